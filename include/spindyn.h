@@ -1,0 +1,220 @@
+/*
+ * spindyn.h -- C ABI of libspindyn.so, the MI355X-native (gfx950 HIP) engine for
+ * the matrix-free spin-1/2 Hamiltonian apply H|psi> and the recursions built on
+ * it (Lanczos / Krylov / Chebyshev / KPM).
+ *
+ * The reference (javahedi/SpinDynamics.jl) has no FFI layer; its de-facto
+ * operator seam is the Julia callable  applyH!(out, psi, model)  handed to every
+ * solver (src/Lanczos.jl:27-29,87-89,196-198,255; src/TimeEvolution/Krylov.jl:
+ * 136-137; src/TimeEvolution/Chebyshev.jl:61-62; src/Hamiltonian.jl:286-288) and
+ * supplied by PublicAPI as Hamiltonian.apply_H! (src/PublicAPI.jl:28,62,70,79).
+ * Each entry point below names the reference function it replaces; the Julia
+ * `ccall` stubs a maintainer would add are in INTEGRATION.md and julia/.
+ *
+ * Conventions
+ *  - plain C types only; every function returns an int status (SD_OK == 0).
+ *  - dtype: SD_F64 (Float64) or SD_C128 (ComplexF64, interleaved re,im).
+ *  - sites are 1-based as in the reference's bond tuples (i, j, J).
+ *  - basis indices are 0-based at this ABI (reference index = idx0 + 1).
+ *  - "host" pointers are caller-owned host memory, only touched during the call.
+ *    "dev" pointers are device (HIP) pointers on the context's device.
+ *  - a sd_model is immutable after creation and may be shared between threads;
+ *    a sd_ctx (device + stream + scratch) must not be used concurrently.
+ */
+#ifndef SPINDYN_H
+#define SPINDYN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* status codes.  Mapping to the reference's Julia exceptions:
+ *   SD_EARG   -> ArgumentError      (src/Basis.jl:10-16, src/SpinModel.jl:80, src/PublicAPI.jl:34,87,152)
+ *   SD_EDIM   -> DimensionMismatch / AssertionError (src/Hamiltonian.jl:63-66,220,289)
+ *   SD_EZERO  -> error("starting vector has zero norm") (src/Lanczos.jl:210-212)
+ */
+#define SD_OK 0
+#define SD_EARG 1
+#define SD_EDIM 2
+#define SD_EZERO 3
+#define SD_ENOMEM 4
+#define SD_EHIP 5
+#define SD_ENODEV 6
+#define SD_EINTERNAL 7
+
+#define SD_F64 1
+#define SD_C128 2
+
+/* KPM damping kernels (src/KPM_Sqw.jl:131-145); anything else = no damping */
+#define SD_KERNEL_JACKSON 0
+#define SD_KERNEL_LORENTZ 1
+#define SD_KERNEL_NONE 2
+/* broadening for the Lanczos spectral function (src/LanczosSqw.jl:29-40) */
+#define SD_BROADEN_LORENTZ 0
+#define SD_BROADEN_GAUSS 1
+
+typedef struct sd_ctx sd_ctx;
+typedef struct sd_model sd_model;
+
+/* ---- library / context ------------------------------------------------ */
+const char *sd_version(void);
+/* number of HIP devices visible (0 when there is no GPU; never fails) */
+int sd_device_count(void);
+/* Creates a context on HIP device `device` with its own stream.  Fails with
+ * SD_ENODEV when no GPU is present: there is no CPU fallback in this library. */
+int sd_ctx_create(int device, sd_ctx **out);
+void sd_ctx_destroy(sd_ctx *ctx);
+/* Use an externally owned hipStream_t (e.g. torch's current stream) for all
+ * launches of this context; NULL restores the context's own stream. */
+int sd_ctx_set_stream(sd_ctx *ctx, void *hip_stream);
+int sd_ctx_synchronize(sd_ctx *ctx);
+/* last error text of this context ("" if none); valid until the next call */
+const char *sd_last_error(const sd_ctx *ctx);
+/* text for a status code */
+const char *sd_status_string(int status);
+
+/* ---- model (replaces SpinModel.Model, src/SpinModel.jl:6-38) ------------ */
+/* nup = -1 selects the full 2^L basis (`nup === nothing`).  states/idxmap are
+ * never passed: the basis order of build_sector_basis (src/Basis.jl:37-53) is
+ * reproduced from closed-form combinatorial ranking.  ctx may be NULL: the
+ * model is then host-only (basis queries work, device applies do not). */
+int sd_model_create(sd_ctx *ctx, int L, int nup,
+                    int n_hop, const int *hop_i, const int *hop_j, const double *hop_J,
+                    int n_zz, const int *zz_i, const int *zz_j, const double *zz_J,
+                    const double *field /* L entries or NULL */, sd_model **out);
+/* XXZChain(L; Jxy, Jz, hz, nup, boundary) -- src/SpinModel.jl:63-90.
+ * boundary: 0 = :open, 1 = :periodic; anything else -> SD_EARG. */
+int sd_xxz_chain(sd_ctx *ctx, int L, double Jxy, double Jz, double hz, int nup, int boundary,
+                 sd_model **out);
+void sd_model_destroy(sd_model *m);
+int64_t sd_model_dim(const sd_model *m);      /* length(model.states) */
+int sd_model_L(const sd_model *m);
+int sd_model_nup(const sd_model *m);          /* -1 for the full basis */
+/* which device path the apply takes: 0 generic (per-row rank/unrank),
+ * 1 tiled (prefix-run tiles, LDS staged suffix hops) */
+int sd_model_path(const sd_model *m);
+/* model.states[start .. start+count)  (host computation, 0-based start) */
+int sd_model_states(const sd_model *m, int64_t start, int64_t count, uint64_t *states_out);
+/* get(model.idxmap, state, 0) - 1 : 0-based index of each state, -1 if absent */
+int sd_model_rank(const sd_model *m, const uint64_t *states, int64_t n, int64_t *idx_out);
+
+/* ---- operator level (replaces applyH!(out, psi, model)) ----------------- */
+/* apply_H!   src/Hamiltonian.jl:211-273.  out is overwritten, must not alias
+ * psi, n must equal sd_model_dim (SD_EDIM otherwise). */
+int sd_apply(sd_ctx *ctx, const sd_model *m, int dtype, void *out_host, const void *psi_host, int64_t n);
+int sd_apply_dev(sd_ctx *ctx, const sd_model *m, int dtype, void *out_dev, const void *psi_dev, int64_t n);
+/* apply_rescaled_H!   src/Hamiltonian.jl:286-301:  out = (H psi - b psi) / a, fused in one pass */
+int sd_apply_rescaled(sd_ctx *ctx, const sd_model *m, int dtype, void *out_host, const void *psi_host,
+                      int64_t n, double a, double b);
+int sd_apply_rescaled_dev(sd_ctx *ctx, const sd_model *m, int dtype, void *out_dev, const void *psi_dev,
+                          int64_t n, double a, double b);
+/* Sz_q_vector   src/Hamiltonian.jl:307-337.  phi_out is always ComplexF64. */
+int sd_szq(sd_ctx *ctx, const sd_model *m, int dtype_in, const void *psi0_host, int64_t n, double q,
+           void *phi_out_host);
+int sd_szq_dev(sd_ctx *ctx, const sd_model *m, int dtype_in, const void *psi0_dev, int64_t n, double q,
+               void *phi_out_dev);
+
+/* Fused Chebyshev term on device vectors (all ComplexF64, length n):
+ *   phi_next = 2*(H phi_curr - b phi_curr)/a - phi_prev ;  psi_t += c * phi_next
+ * = one iteration of src/TimeEvolution/Chebyshev.jl:110-121 in a single pass. */
+int sd_cheb_step_dev(sd_ctx *ctx, const sd_model *m, void *phi_next_dev, const void *phi_curr_dev,
+                     const void *phi_prev_dev, void *psi_t_dev, int64_t n, double a, double b,
+                     double c_re, double c_im);
+
+/* Timed loop for benchmarks: `reps` applies out<-H psi (ping-pong between the
+ * two buffers) bracketed by hipEvents on the context's stream; returns the
+ * average milliseconds per apply.  Both buffers are device pointers. */
+int sd_bench_apply_dev(sd_ctx *ctx, const sd_model *m, int dtype, void *buf_a_dev, void *buf_b_dev,
+                       int64_t n, int reps, float *ms_per_apply);
+
+/* ---- recursion level ---------------------------------------------------- */
+/* All vectors are host arrays; the recursion runs entirely on the device
+ * (apply kernel + BLAS-1 kernels), only scalars cross per iteration.
+ * psi0 arguments marked "or NULL" are drawn from the library's counter-based
+ * normal generator keyed by `seed` when NULL (the reference uses Julia's
+ * randn, whose stream cannot be reproduced outside Julia). */
+
+/* lanczos_extremal   src/Lanczos.jl:27-84   (ComplexF64 start vector) */
+int sd_lanczos_extremal(sd_ctx *ctx, const sd_model *m, int lanc_m, double tol,
+                        const void *psi0_c128_host /* or NULL */, uint64_t seed, int negate,
+                        double *emin, double *emax);
+/* estimate_energy_bounds   src/Lanczos.jl:255-271 */
+int sd_energy_bounds(sd_ctx *ctx, const sd_model *m, int lanc_m,
+                     const void *psi0_a_c128_host /* or NULL */, const void *psi0_b_c128_host /* or NULL */,
+                     uint64_t seed, double *emin, double *emax);
+/* lanczos_groundstate   src/Lanczos.jl:87-181   (Float64, full re-orthogonalisation) */
+int sd_lanczos_groundstate(sd_ctx *ctx, const sd_model *m, int lanc_m, double tol, double orth_tol,
+                           const double *psi0_host /* or NULL */, uint64_t seed,
+                           double *E0, double *psi_gs_host /* n doubles */, int *m_actual);
+/* lanczos_tridiag   src/Lanczos.jl:196-246.  alpha_out[min(lanc_m,n)], beta_out[min(lanc_m,n)-1] */
+int sd_lanczos_tridiag(sd_ctx *ctx, const sd_model *m, const void *v_c128_host, int64_t n, int lanc_m,
+                       double tol, double *alpha_out, double *beta_out, int *m_eff, double *norm_v);
+/* krylov_time_evolve   src/TimeEvolution/Krylov.jl:136-192.  psit_out is ComplexF64. */
+int sd_krylov_evolve(sd_ctx *ctx, const sd_model *m, int dtype, const void *psi0_host, int64_t n,
+                     double dt, int kry_m, void *psit_out_c128_host);
+/* chebyshev_time_evolve   src/TimeEvolution/Chebyshev.jl:61-124  (psi0 ComplexF64) */
+int sd_chebyshev_evolve(sd_ctx *ctx, const sd_model *m, const void *psi0_c128_host, int64_t n, double dt,
+                        int cheb_n, double Emin, double Emax, void *psit_out_c128_host);
+/* compute_chebyshev_moments   src/KPM_Sqw.jl:95-128 */
+int sd_kpm_moments(sd_ctx *ctx, const sd_model *m, const void *phi_c128_host, int64_t n, int M,
+                   double a, double b, double *mu_out);
+/* get_kernel   src/KPM_Sqw.jl:131-145 (host) */
+int sd_kpm_kernel(int M, int kernel, double *g_out);
+/* _rescaling_from_bounds   src/KPM_Sqw.jl:13-17 (host) */
+int sd_kpm_rescaling_from_bounds(double Emin, double Emax, double *a, double *b);
+/* reconstruction part of kpm_sw   src/KPM_Sqw.jl:55-90 (host), moments already damped */
+int sd_kpm_reconstruct(const double *mu_damped, int kpm_m, const double *omega, int W, double a, double b,
+                       double E0, double *S_out);
+/* kpm_sqw   src/KPM_Sqw.jl:191-256.  Smat_out is Qn x W row-major.  When
+ * have_ab == 0 the rescaling is estimated as the reference does (two Lanczos
+ * runs, lanc_m = 80) with generated start vectors keyed by `seed`. */
+int sd_kpm_sqw(sd_ctx *ctx, const sd_model *m, int dtype, const void *psi0_host, int64_t n,
+               const double *q, int Qn, const double *omega, int W, int have_ab, double a, double b,
+               int kpm_m, int kernel, uint64_t seed, double *Smat_out);
+/* spectral_from_tridiagonal   src/LanczosSqw.jl:18-43 (host) */
+int sd_spectral_from_tridiagonal(const double *alpha, const double *beta, int m, double norm_phi, double E0,
+                                 const double *omega, int W, double eta, int broaden, double *S_out);
+/* lanczos_sqw   src/LanczosSqw.jl:49-80 */
+int sd_lanczos_sqw(sd_ctx *ctx, const sd_model *m, int dtype, const void *psi0_host, int64_t n,
+                   const double *q, int Qn, const double *omega, int W, int lanc_m, double eta, int broaden,
+                   double *Smat_out);
+
+/* ---- host utilities ------------------------------------------------------ */
+/* eigen(SymTridiagonal(d, e)): ascending eigenvalues w[n]; z (n*n column-major) may be NULL */
+int sd_symtridiag_eig(int n, const double *d, const double *e, double *w, double *z);
+/* Chebyshev expansion coefficients c_k (src/TimeEvolution/Chebyshev.jl:74-79); c_out has 2*cheb_n doubles */
+int sd_chebyshev_coeffs(int cheb_n, double a, double b, double dt, double *c_out);
+/* counter-based N(0,1) generator used for synthetic vectors: element k of the
+ * stream (seed) -- identical on host and device, independent of sharding. */
+int sd_fill_randn_dev(sd_ctx *ctx, void *x_dev, int64_t n_doubles, uint64_t seed, uint64_t first_index);
+int sd_fill_randn_host(double *x, int64_t n_doubles, uint64_t seed, uint64_t first_index);
+
+/* ---- index-range sharding (multi-GPU; one process per GPU) -------------- */
+/* A shard owns the contiguous basis-index range [row_lo, row_hi) (aligned to
+ * tile boundaries).  Vectors of a sharded model are device arrays of
+ * n_local + n_halo elements: the first n_local are the owned rows, the tail is
+ * the halo filled by the exchange (RCCL send/recv driven by the host layer)
+ * before each apply.  The plan lists contiguous slabs to send / receive. */
+typedef struct sd_shard_info {
+  int rank, nranks;
+  int64_t row_lo, row_hi;   /* owned global rows */
+  int64_t n_local, n_halo;  /* elements */
+  int64_t n_recv_slabs, n_send_slabs;
+} sd_shard_info;
+typedef struct sd_slab {
+  int peer;                 /* rank on the other side */
+  int64_t local_offset;     /* element offset in THIS rank's vector (send: within owned rows; recv: >= n_local) */
+  int64_t count;            /* elements */
+} sd_slab;
+/* Re-plans the model as shard `rank` of `nranks` (nranks == 1 restores the
+ * unsharded plan).  Must be called before any apply on that model. */
+int sd_model_set_shard(sd_model *m, int rank, int nranks);
+int sd_model_shard_info(const sd_model *m, sd_shard_info *out);
+int sd_model_shard_slabs(const sd_model *m, sd_slab *recv_out, sd_slab *send_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPINDYN_H */

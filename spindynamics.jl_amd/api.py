@@ -1,0 +1,38 @@
+"""Mirror of the reference's PublicAPI module (src/PublicAPI.jl:25-155): same
+function names, keyword arguments and dispatch on `method`; Julia Symbols are
+Python strings ("lanczos", "krylov", "chebyshev", "kpm")."""
+import numpy as np
+
+from ._lib import ArgumentError
+from .hamiltonian import apply_H
+from . import solvers
+
+
+def groundstate(model, method="lanczos", **kwargs):
+    """groundstate(model; method=:lanczos, kwargs...) -> (E0, psi) -- src/PublicAPI.jl:25-35"""
+    if method == "lanczos":
+        return solvers.lanczos_groundstate(apply_H, model, **kwargs)
+    raise ArgumentError(f"unsupported ground-state method: {method}")
+
+
+def time_evolve(model, psi0, t, method="krylov", Ebounds=None, **kwargs):
+    """time_evolve(model, psi0, t; method=:krylov, Ebounds=nothing, kwargs...) -- src/PublicAPI.jl:50-88"""
+    if method == "krylov":
+        return solvers.krylov_time_evolve(psi0, float(t), apply_H, model, **kwargs)
+    if method == "chebyshev":
+        seed = kwargs.pop("seed", 0)
+        bounds = solvers.estimate_energy_bounds(apply_H, model, seed=seed) if Ebounds is None else Ebounds
+        return solvers.chebyshev_time_evolve(psi0, float(t), apply_H, model, Ebounds=bounds, **kwargs)
+    raise ArgumentError(f"unsupported time-evolution method: {method}")
+
+
+def dynamical_structure_factor(model, psi0, q, omega, method="lanczos", **kwargs):
+    """dynamical_structure_factor(model, psi0, q, omega; method=:lanczos, kwargs...) -> S[len(q), len(omega)]
+    -- src/PublicAPI.jl:122-155"""
+    q_list = np.asarray(q, dtype=np.float64)
+    w = np.asarray(omega, dtype=np.float64)
+    if method == "lanczos":
+        return solvers.lanczos_sqw(psi0, model, q_list, w, **kwargs)
+    if method == "kpm":
+        return solvers.kpm_sqw(psi0, model, q_list, w, **kwargs)
+    raise ArgumentError(f"unsupported dynamical structure-factor method: {method}")

@@ -1,0 +1,326 @@
+// Host-side construction of the basis tables and the (optionally sharded)
+// tile plan.  Reproduces the order of build_sector_basis (reference
+// src/Basis.jl:37-53) from binomial coefficients only: no states[] array and
+// no hash map are ever built for the full dimension.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+#include "sd_internal.hpp"
+
+int64_t sd_binom(int n, int k) {
+  if (k < 0 || k > n || n < 0) return 0;
+  if (k > n - k) k = n - k;
+  __int128 r = 1;
+  for (int i = 1; i <= k; ++i) r = r * (n - k + i) / i;
+  return (int64_t)r;
+}
+
+void sd_fill_binom(std::vector<int64_t> &tab) {
+  const int W = SD_MAX_L + 1;
+  tab.assign((size_t)W * W, 0);
+  for (int n = 0; n < W; ++n)
+    for (int k = 0; k <= n; ++k) tab[(size_t)n * W + k] = sd_binom(n, k);
+}
+
+static inline int64_t B(const sd_model *m, int n, int k) {
+  if (k < 0 || n < 0 || k > n) return 0;
+  return m->binom[(size_t)n * (SD_MAX_L + 1) + k];
+}
+
+// idx0 -> state: walk sites 1..L, "up" child first.
+uint64_t sd_unrank_host(const sd_model *m, int64_t idx0) {
+  if (m->nup < 0) return (uint64_t)idx0;
+  uint64_t s = 0;
+  int r = m->nup;
+  for (int k = 1; k <= m->L && r > 0; ++k) {
+    int64_t c = B(m, m->L - k, r - 1);  // rows with site k up
+    if (idx0 < c) { s |= (uint64_t)1 << (k - 1); --r; }
+    else idx0 -= c;
+  }
+  return s;
+}
+
+// state -> idx0, -1 when s is not a basis state (get(idxmap, s, 0) == 0)
+int64_t sd_rank_host(const sd_model *m, uint64_t s) {
+  if (m->L < 64 && (s >> m->L) != 0) return -1;
+  if (m->nup < 0) return (int64_t)s;
+  if (__builtin_popcountll(s) != m->nup) return -1;
+  int64_t idx = 0;
+  int r = m->nup;
+  for (int k = 1; k <= m->L && r > 0; ++k) {
+    if ((s >> (k - 1)) & 1) --r;
+    else idx += B(m, m->L - k, r - 1);
+  }
+  return idx;
+}
+
+// Enumerate the sector (n sites, t ups) in reference order into out (as n-bit ints).
+static void enum_sector(int n, int t, std::vector<uint16_t> &out) {
+  if (t < 0 || t > n) return;
+  std::vector<int> c(t);
+  for (int k = 0; k < t; ++k) c[k] = k + 1;
+  for (;;) {
+    uint32_t s = 0;
+    for (int k = 0; k < t; ++k) s |= 1u << (c[k] - 1);
+    out.push_back((uint16_t)s);
+    int k = t - 1;
+    while (k >= 0 && c[k] == n - t + k + 1) --k;
+    if (k < 0) break;
+    ++c[k];
+    for (int q = k + 1; q < t; ++q) c[q] = c[q - 1] + 1;
+  }
+}
+
+static int suffix_bits_from_env() {
+  int ls = 14;
+  if (const char *e = getenv("SD_SUFFIX_BITS")) ls = atoi(e);
+  if (ls < 2) ls = 2;
+  if (ls > 16) ls = 16;
+  return ls;
+}
+
+// base row (global) of the tile with prefix P
+static int64_t tile_base_global(const sd_model *m, uint32_t P) {
+  int64_t idx = 0;
+  int r = m->nup;
+  for (int k = 1; k <= m->p && r > 0; ++k) {
+    if ((P >> (k - 1)) & 1) --r;
+    else idx += B(m, m->L - k, r - 1);
+  }
+  return idx;
+}
+
+struct TileRef { int64_t base; uint32_t P; };
+
+// marks in need[] every tile (by prefix) that the rows of tiles [k_lo,k_hi) read through a hop
+static void collect_needs(const sd_model *m, const std::vector<TileRef> &tiles, size_t k_lo, size_t k_hi,
+                          int nn_hops, std::vector<uint8_t> &need) {
+  const int p = m->p;
+  for (size_t k = k_lo; k < k_hi; ++k) {
+    uint32_t P = tiles[k].P;
+    if (nn_hops > 0) {
+      for (int b = 1; b <= p - 1; ++b)
+        if (((P >> (b - 1)) & 1) != ((P >> b) & 1)) need[P ^ (3u << (b - 1))] = 1;
+      if (p >= 1) {
+        uint32_t Q = P ^ (1u << (p - 1));
+        int t2 = m->nup - __builtin_popcount(Q);
+        if (t2 >= 0 && t2 <= m->LS) need[Q] = 1;
+      }
+    }
+    for (size_t h = (size_t)nn_hops; h < m->hop_i.size(); ++h) {
+      int i = m->hop_i[h], j = m->hop_j[h];
+      bool ip = i <= p, jp = j <= p;
+      uint32_t Q = P;
+      if (ip && jp) {
+        if (((P >> (i - 1)) & 1) == ((P >> (j - 1)) & 1)) continue;
+        Q = P ^ (1u << (i - 1)) ^ (1u << (j - 1));
+      } else if (ip) Q = P ^ (1u << (i - 1));
+      else if (jp) Q = P ^ (1u << (j - 1));
+      else continue;
+      int t2 = m->nup - __builtin_popcount(Q);
+      if (t2 >= 0 && t2 <= m->LS) need[Q] = 1;
+    }
+  }
+}
+
+static int count_nn_hops(const sd_model *m) {
+  int L = m->L;
+  if (L < 2 || (int)m->hop_i.size() < L - 1) return 0;
+  for (int k = 0; k < L - 1; ++k)
+    if (m->hop_i[k] != k + 1 || m->hop_j[k] != k + 2) return 0;
+  return L - 1;
+}
+
+int sd_build_plan(sd_model *m, int rank, int nranks, std::string &err) {
+  if (nranks < 1 || rank < 0 || rank >= nranks) { err = "bad shard rank/nranks"; return SD_EARG; }
+  m->rank = rank; m->nranks = nranks;
+  m->tile_prefix.clear(); m->tile_base.clear(); m->addr.clear();
+  m->suf_states.clear(); m->suf_rank.clear(); m->suf_off.clear();
+  m->recv_slabs.clear(); m->send_slabs.clear();
+  m->n_halo = 0; m->max_tile_len = 0;
+
+  const int L = m->L;
+  int LS = std::min(L, suffix_bits_from_env());
+  int p = L - LS;
+  if (m->nup < 0 || p > SD_MAX_PREFIX_BITS) {
+    // generic (untiled) path: per-row rank/unrank on device
+    if (nranks != 1) { err = "sharding needs a fixed-nup sector with at most 2^26 prefix tiles"; return SD_EARG; }
+    m->p = -1; m->LS = 0;
+    m->row_lo = 0; m->row_hi = m->N; m->n_local = m->N;
+    return SD_OK;
+  }
+  m->p = p; m->LS = LS;
+
+  // suffix sector tables
+  m->suf_off.assign(LS + 2, 0);
+  m->suf_rank.assign((size_t)1 << LS, 0);
+  for (int t = 0; t <= LS; ++t) {
+    m->suf_off[t] = (int32_t)m->suf_states.size();
+    enum_sector(LS, t, m->suf_states);
+    int32_t n = (int32_t)m->suf_states.size() - m->suf_off[t];
+    for (int32_t i = 0; i < n; ++i) m->suf_rank[m->suf_states[m->suf_off[t] + i]] = (uint16_t)i;
+  }
+  m->suf_off[LS + 1] = (int32_t)m->suf_states.size();
+
+  // all feasible tiles in natural (row) order
+  std::vector<TileRef> tiles;
+  const uint32_t nP = 1u << p;
+  for (uint32_t P = 0; P < nP; ++P) {
+    int t2 = m->nup - __builtin_popcount(P);
+    if (t2 < 0 || t2 > LS) continue;
+    tiles.push_back({tile_base_global(m, P), P});
+  }
+  std::sort(tiles.begin(), tiles.end(), [](const TileRef &a, const TileRef &b) { return a.base < b.base; });
+  const size_t T = tiles.size();
+  if (T == 0) { err = "empty basis"; return SD_EINTERNAL; }
+
+  // shard boundaries (tile aligned)
+  std::vector<size_t> kb(nranks + 1, 0);
+  for (int r = 1; r < nranks; ++r) {
+    int64_t target = (int64_t)((__int128)m->N * r / nranks);
+    size_t k = std::lower_bound(tiles.begin(), tiles.end(), target,
+                                [](const TileRef &a, int64_t v) { return a.base < v; }) - tiles.begin();
+    kb[r] = std::max(k, kb[r - 1]);
+  }
+  kb[nranks] = T;
+  auto row_of = [&](size_t k) { return k < T ? tiles[k].base : m->N; };
+  auto owner_of = [&](int64_t base) {
+    int r = 0;
+    while (r + 1 < nranks && base >= row_of(kb[r + 1])) ++r;
+    return r;
+  };
+  m->row_lo = row_of(kb[rank]); m->row_hi = row_of(kb[rank + 1]);
+  m->n_local = m->row_hi - m->row_lo;
+
+  m->addr.assign(nP, -1);
+  for (size_t k = kb[rank]; k < kb[rank + 1]; ++k) {
+    m->tile_prefix.push_back(tiles[k].P);
+    m->tile_base.push_back(tiles[k].base - m->row_lo);
+    m->addr[tiles[k].P] = tiles[k].base - m->row_lo;
+    int t2 = m->nup - __builtin_popcount(tiles[k].P);
+    m->max_tile_len = std::max<int>(m->max_tile_len, (int)B(m, LS, t2));
+  }
+
+  if (nranks > 1) {
+    const int nn = count_nn_hops(m);
+    std::vector<uint8_t> need(nP);
+    for (int q = 0; q < nranks; ++q) {
+      std::fill(need.begin(), need.end(), 0);
+      collect_needs(m, tiles, kb[q], kb[q + 1], nn, need);
+      // walk all tiles in global order; tiles needed by q and owned by someone else form q's halo
+      int64_t halo_off = row_of(kb[q + 1]) - row_of(kb[q]);  // q's n_local
+      sd_slab cur{-1, 0, 0};
+      int64_t cur_end_global = -1;
+      auto flush = [&]() {
+        if (cur.count == 0) return;
+        if (q == rank) m->recv_slabs.push_back(cur);
+        cur.count = 0;
+      };
+      for (size_t k = 0; k < T; ++k) {
+        if (!need[tiles[k].P]) continue;
+        if (k >= kb[q] && k < kb[q + 1]) continue;  // q owns it
+        int own = owner_of(tiles[k].base);
+        int t2 = m->nup - __builtin_popcount(tiles[k].P);
+        int64_t len = B(m, LS, t2);
+        if (q == rank) {
+          m->addr[tiles[k].P] = halo_off;
+          if (cur.count > 0 && cur.peer == own && cur_end_global == tiles[k].base) cur.count += len;
+          else { flush(); cur = {own, halo_off, len}; }
+          cur_end_global = tiles[k].base + len;
+        } else if (own == rank) {
+          // q needs one of my tiles: a send slab (merged exactly like q merges its receives)
+          int64_t loc = tiles[k].base - m->row_lo;
+          if (!m->send_slabs.empty() && m->send_slabs.back().peer == q &&
+              m->send_slabs.back().local_offset + m->send_slabs.back().count == loc)
+            m->send_slabs.back().count += len;
+          else m->send_slabs.push_back({q, loc, len});
+        }
+        halo_off += len;
+      }
+      flush();
+      if (q == rank) m->n_halo = halo_off - m->n_local;
+    }
+  }
+  return SD_OK;
+}
+
+// uniform-exact diagonal: every partial sum k*q (k <= n) is representable
+static bool exact_multiples(double q, int n) {
+  for (int k = 1; k <= n; ++k)
+    if (std::fma((double)k, q, -((double)k * q)) != 0.0) return false;
+  return true;
+}
+
+template <class T>
+static int up(sd_model *m, const std::vector<T> &v, const T **dst, std::string &err) {
+  *dst = nullptr;
+  size_t bytes = sizeof(T) * std::max<size_t>(v.size(), 1);
+  void *d = nullptr;
+  hipError_t e = hipMalloc(&d, bytes);
+  if (e != hipSuccess) { err = std::string("hipMalloc: ") + hipGetErrorString(e); return SD_ENOMEM; }
+  m->dev_allocs.push_back(d);
+  if (!v.empty()) {
+    e = hipMemcpy(d, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { err = std::string("hipMemcpy: ") + hipGetErrorString(e); return SD_EHIP; }
+  }
+  *dst = (const T *)d;
+  return SD_OK;
+}
+
+void sd_free_device_tables(sd_model *m) {
+  for (void *d : m->dev_allocs) (void)hipFree(d);
+  m->dev_allocs.clear();
+  m->dev_ready = false;
+}
+
+int sd_upload_model(sd_model *m, std::string &err) {
+  sd_free_device_tables(m);
+  sd_dev_model &d = m->dm;
+  memset(&d, 0, sizeof(d));
+  d.L = m->L; d.nup = m->nup; d.p = m->p; d.LS = m->LS;
+  d.n_hop = (int)m->hop_i.size(); d.n_zz = (int)m->zz_i.size();
+  d.N = m->N; d.n_local = m->n_local; d.row_lo = m->row_lo;
+  d.nn_hops = (m->p >= 0) ? count_nn_hops(m) : 0;
+  d.field_zero = 1;
+  for (double h : m->field) if (h != 0.0) d.field_zero = 0;
+  // closed-form diagonal when it is bit-identical to the reference's sequential sum
+  d.diag_mode = 0; d.diag_q = 0.0; d.n_zz_nn = 0;
+  if (d.field_zero) {
+    bool uniform = true;
+    for (double J : m->zz_J) if (J != m->zz_J[0]) uniform = false;
+    if (m->zz_J.empty()) { d.diag_mode = 1; d.diag_q = 0.0; }
+    else if (uniform) {
+      double q = (m->zz_J[0] * 0.5) * 0.5;
+      if (exact_multiples(q, (int)m->zz_J.size())) { d.diag_mode = 1; d.diag_q = q; }
+    }
+    if (d.diag_mode == 1 && m->L >= 2 && (int)m->zz_i.size() >= m->L - 1) {
+      bool nn = true;
+      for (int k = 0; k < m->L - 1; ++k)
+        if (m->zz_i[k] != k + 1 || m->zz_j[k] != k + 2) nn = false;
+      if (nn) d.n_zz_nn = m->L - 1;
+    }
+  }
+  if (getenv("SD_EXACT_DIAG")) d.diag_mode = 0;
+  int rc;
+  if ((rc = up(m, m->hop_i, &d.hop_i, err))) return rc;
+  if ((rc = up(m, m->hop_j, &d.hop_j, err))) return rc;
+  if ((rc = up(m, m->hop_J, &d.hop_J, err))) return rc;
+  if ((rc = up(m, m->zz_i, &d.zz_i, err))) return rc;
+  if ((rc = up(m, m->zz_j, &d.zz_j, err))) return rc;
+  if ((rc = up(m, m->zz_J, &d.zz_J, err))) return rc;
+  if ((rc = up(m, m->field, &d.field, err))) return rc;
+  if ((rc = up(m, m->binom, &d.binom, err))) return rc;
+  d.n_tiles = (int)m->tile_prefix.size();
+  if (m->p >= 0) {
+    if ((rc = up(m, m->tile_prefix, &d.tile_prefix, err))) return rc;
+    if ((rc = up(m, m->tile_base, &d.tile_base, err))) return rc;
+    if ((rc = up(m, m->addr, &d.addr, err))) return rc;
+    if ((rc = up(m, m->suf_states, &d.suf_states, err))) return rc;
+    if ((rc = up(m, m->suf_off, &d.suf_off, err))) return rc;
+    if ((rc = up(m, m->suf_rank, &d.suf_rank, err))) return rc;
+  }
+  m->dev_ready = true;
+  return SD_OK;
+}

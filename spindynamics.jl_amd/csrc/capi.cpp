@@ -1,0 +1,334 @@
+// C ABI: contexts, models, operator-level entry points (include/spindyn.h).
+#include <cmath>
+#include <cstring>
+#include <new>
+
+#include "sd_internal.hpp"
+
+int sd_set_err(sd_ctx *ctx, int code, const std::string &msg) {
+  if (ctx) ctx->err = msg;
+  return code;
+}
+
+namespace {
+thread_local std::string g_err;  // errors raised without a context
+
+int fail(sd_ctx *ctx, int code, const std::string &msg) {
+  g_err = msg;
+  return sd_set_err(ctx, code, msg);
+}
+
+struct TmpDev {
+  sd_ctx *ctx;
+  void *p = nullptr;
+  explicit TmpDev(sd_ctx *c) : ctx(c) {}
+  ~TmpDev() { if (p) (void)hipFree(p); }
+  int alloc(size_t bytes) {
+    hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
+    if (e != hipSuccess) return sd_set_err(ctx, SD_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    return SD_OK;
+  }
+};
+
+int check_apply_args(sd_ctx *ctx, const sd_model *m, int dtype, const void *out, const void *psi, int64_t n) {
+  if (!ctx) return SD_EARG;
+  if (!m) return sd_set_err(ctx, SD_EARG, "null model");
+  if (!m->dev_ready) return sd_set_err(ctx, SD_EARG, "model has no device tables (created without a context)");
+  if (dtype != SD_F64 && dtype != SD_C128) return sd_set_err(ctx, SD_EARG, "dtype must be SD_F64 or SD_C128");
+  if (!out || !psi) return sd_set_err(ctx, SD_EARG, "null vector");
+  if (out == psi) return sd_set_err(ctx, SD_EARG, "out must not alias psi");
+  return SD_OK;
+}
+}  // namespace
+
+extern "C" {
+
+const char *sd_version(void) { return "spindyn-mi355x 0.1 (gfx950)"; }
+
+int sd_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+const char *sd_status_string(int status) {
+  switch (status) {
+    case SD_OK: return "ok";
+    case SD_EARG: return "invalid argument";
+    case SD_EDIM: return "dimension mismatch";
+    case SD_EZERO: return "starting vector has zero norm";
+    case SD_ENOMEM: return "out of memory";
+    case SD_EHIP: return "HIP error";
+    case SD_ENODEV: return "no HIP device";
+    case SD_EINTERNAL: return "internal error";
+    default: return "unknown status";
+  }
+}
+
+int sd_ctx_create(int device, sd_ctx **out) {
+  if (!out) return SD_EARG;
+  *out = nullptr;
+  int n = sd_device_count();
+  if (n <= 0) return fail(nullptr, SD_ENODEV, "no HIP device: libspindyn has no CPU fallback");
+  if (device < 0 || device >= n) return fail(nullptr, SD_EARG, "device index out of range");
+  sd_ctx *c = new (std::nothrow) sd_ctx();
+  if (!c) return SD_ENOMEM;
+  c->device = device;
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&c->own_stream) != hipSuccess) {
+    delete c;
+    return fail(nullptr, SD_EHIP, "hipSetDevice/hipStreamCreate failed");
+  }
+  c->stream = c->own_stream;
+  if (hipMalloc((void **)&c->d_scalars, 16 * sizeof(double)) != hipSuccess ||
+      hipHostMalloc((void **)&c->h_scalars, 16 * sizeof(double)) != hipSuccess ||
+      hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+    sd_ctx_destroy(c);
+    return fail(nullptr, SD_EHIP, "context allocation failed");
+  }
+  (void)hipMemset(c->d_scalars, 0, 16 * sizeof(double));
+  *out = c;
+  return SD_OK;
+}
+
+void sd_ctx_destroy(sd_ctx *c) {
+  if (!c) return;
+  if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
+  if (c->d_partials) (void)hipFree(c->d_partials);
+  if (c->d_scalars) (void)hipFree(c->d_scalars);
+  if (c->h_scalars) (void)hipHostFree(c->h_scalars);
+  if (c->ev0) (void)hipEventDestroy(c->ev0);
+  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  delete c;
+}
+
+int sd_ctx_set_stream(sd_ctx *ctx, void *hip_stream) {
+  if (!ctx) return SD_EARG;
+  ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+  return SD_OK;
+}
+
+int sd_ctx_synchronize(sd_ctx *ctx) {
+  if (!ctx) return SD_EARG;
+  SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SD_OK;
+}
+
+const char *sd_last_error(const sd_ctx *ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+
+int sd_model_create(sd_ctx *ctx, int L, int nup, int n_hop, const int *hop_i, const int *hop_j, const double *hop_J,
+                    int n_zz, const int *zz_i, const int *zz_j, const double *zz_J, const double *field,
+                    sd_model **out) {
+  if (!out) return SD_EARG;
+  *out = nullptr;
+  // src/Basis.jl:9-20 _validate_basis_args
+  if (L < 1) return fail(ctx, SD_EARG, "L must be at least 1");
+  if (L > SD_MAX_L) return fail(ctx, SD_EARG, "L must be at most 63 when using UInt64 basis states");
+  if (nup < -1 || nup > L) return fail(ctx, SD_EARG, "nup must satisfy 0 <= nup <= L");
+  if (n_hop < 0 || n_zz < 0 || n_hop > SD_MAX_BONDS || n_zz > SD_MAX_BONDS) return fail(ctx, SD_EARG, "bad bond count");
+  if ((n_hop && (!hop_i || !hop_j || !hop_J)) || (n_zz && (!zz_i || !zz_j || !zz_J))) return fail(ctx, SD_EARG, "null bond list");
+  for (int k = 0; k < n_hop; ++k)
+    if (hop_i[k] < 1 || hop_i[k] > L || hop_j[k] < 1 || hop_j[k] > L || hop_i[k] == hop_j[k])
+      return fail(ctx, SD_EARG, "hopping bond site out of range");
+  for (int k = 0; k < n_zz; ++k)
+    if (zz_i[k] < 1 || zz_i[k] > L || zz_j[k] < 1 || zz_j[k] > L) return fail(ctx, SD_EARG, "zz bond site out of range");
+  sd_model *m = new (std::nothrow) sd_model();
+  if (!m) return SD_ENOMEM;
+  m->ctx = ctx; m->L = L; m->nup = nup;
+  m->hop_i.assign(hop_i, hop_i + n_hop); m->hop_j.assign(hop_j, hop_j + n_hop); m->hop_J.assign(hop_J, hop_J + n_hop);
+  m->zz_i.assign(zz_i, zz_i + n_zz); m->zz_j.assign(zz_j, zz_j + n_zz); m->zz_J.assign(zz_J, zz_J + n_zz);
+  m->field.assign(L, 0.0);
+  if (field) m->field.assign(field, field + L);
+  sd_fill_binom(m->binom);
+  m->N = nup < 0 ? ((int64_t)1 << L) : sd_binom(L, nup);
+  std::string err;
+  int rc = sd_build_plan(m, 0, 1, err);
+  if (!rc && ctx) {
+    if (hipSetDevice(ctx->device) != hipSuccess) { rc = SD_EHIP; err = "hipSetDevice failed"; }
+    else rc = sd_upload_model(m, err);
+  }
+  if (rc) { sd_model_destroy(m); return fail(ctx, rc, err); }
+  *out = m;
+  return SD_OK;
+}
+
+int sd_xxz_chain(sd_ctx *ctx, int L, double Jxy, double Jz, double hz, int nup, int boundary, sd_model **out) {
+  if (!out) return SD_EARG;
+  *out = nullptr;
+  if (boundary != 0 && boundary != 1) return fail(ctx, SD_EARG, "boundary must be :open or :periodic");
+  if (L < 1 || L > SD_MAX_L) return fail(ctx, SD_EARG, "L must satisfy 1 <= L <= 63");
+  int hi[SD_MAX_L + 1], hj[SD_MAX_L + 1];
+  double hJ[SD_MAX_L + 1], zJ[SD_MAX_L + 1], f[SD_MAX_L + 1];
+  int nb = 0;
+  for (int i = 1; i <= L - 1; ++i) { hi[nb] = i; hj[nb] = i + 1; hJ[nb] = Jxy / 2; zJ[nb] = Jz; ++nb; }   // src/SpinModel.jl:71-72
+  if (boundary == 1 && L > 2) { hi[nb] = L; hj[nb] = 1; hJ[nb] = Jxy / 2; zJ[nb] = Jz; ++nb; }           // :74-78
+  for (int i = 0; i < L; ++i) f[i] = hz;                                                              // :87
+  return sd_model_create(ctx, L, nup, nb, hi, hj, hJ, nb, hi, hj, zJ, f, out);
+}
+
+void sd_model_destroy(sd_model *m) {
+  if (!m) return;
+  sd_free_device_tables(m);
+  delete m;
+}
+
+int64_t sd_model_dim(const sd_model *m) { return m ? m->N : -1; }
+int sd_model_L(const sd_model *m) { return m ? m->L : -1; }
+int sd_model_nup(const sd_model *m) { return m ? m->nup : -2; }
+int sd_model_path(const sd_model *m) { return (m && m->p >= 0) ? 1 : 0; }
+
+int sd_model_states(const sd_model *m, int64_t start, int64_t count, uint64_t *out) {
+  if (!m || !out || start < 0 || count < 0 || start + count > m->N) return SD_EARG;
+  for (int64_t i = 0; i < count; ++i) out[i] = sd_unrank_host(m, start + i);
+  return SD_OK;
+}
+
+int sd_model_rank(const sd_model *m, const uint64_t *states, int64_t n, int64_t *idx) {
+  if (!m || !states || !idx || n < 0) return SD_EARG;
+  for (int64_t i = 0; i < n; ++i) idx[i] = sd_rank_host(m, states[i]);
+  return SD_OK;
+}
+
+int sd_model_set_shard(sd_model *m, int rank, int nranks) {
+  if (!m) return SD_EARG;
+  std::string err;
+  int rc = sd_build_plan(m, rank, nranks, err);
+  if (!rc && m->ctx) {
+    if (hipSetDevice(m->ctx->device) != hipSuccess) { rc = SD_EHIP; err = "hipSetDevice failed"; }
+    else rc = sd_upload_model(m, err);
+  }
+  if (rc) return fail(m->ctx, rc, err);
+  return SD_OK;
+}
+
+int sd_model_shard_info(const sd_model *m, sd_shard_info *out) {
+  if (!m || !out) return SD_EARG;
+  out->rank = m->rank; out->nranks = m->nranks;
+  out->row_lo = m->row_lo; out->row_hi = m->row_hi;
+  out->n_local = m->n_local; out->n_halo = m->n_halo;
+  out->n_recv_slabs = (int64_t)m->recv_slabs.size(); out->n_send_slabs = (int64_t)m->send_slabs.size();
+  return SD_OK;
+}
+
+int sd_model_shard_slabs(const sd_model *m, sd_slab *recv_out, sd_slab *send_out) {
+  if (!m) return SD_EARG;
+  if (recv_out) for (size_t i = 0; i < m->recv_slabs.size(); ++i) recv_out[i] = m->recv_slabs[i];
+  if (send_out) for (size_t i = 0; i < m->send_slabs.size(); ++i) send_out[i] = m->send_slabs[i];
+  return SD_OK;
+}
+
+// ---- operator level ----
+
+int sd_apply_dev(sd_ctx *ctx, const sd_model *m, int dtype, void *out, const void *psi, int64_t n) {
+  int rc = check_apply_args(ctx, m, dtype, out, psi, n);
+  if (rc) return rc;
+  if (n != m->n_local) return sd_set_err(ctx, SD_EDIM, "vector length does not match the (local) basis dimension");
+  sd_epi_args ea;
+  return sd_launch_apply(ctx, m, dtype, out, psi, SD_EPI_PLAIN, ea);
+}
+
+int sd_apply_rescaled_dev(sd_ctx *ctx, const sd_model *m, int dtype, void *out, const void *psi, int64_t n, double a,
+                          double b) {
+  int rc = check_apply_args(ctx, m, dtype, out, psi, n);
+  if (rc) return rc;
+  if (n != m->n_local) return sd_set_err(ctx, SD_EDIM, "vector length does not match the (local) basis dimension");
+  sd_epi_args ea; ea.a = a; ea.b = b;
+  return sd_launch_apply(ctx, m, dtype, out, psi, SD_EPI_RESCALE, ea);
+}
+
+int sd_cheb_step_dev(sd_ctx *ctx, const sd_model *m, void *phi_next, const void *phi_curr, const void *phi_prev,
+                     void *psi_t, int64_t n, double a, double b, double c_re, double c_im) {
+  int rc = check_apply_args(ctx, m, SD_C128, phi_next, phi_curr, n);
+  if (rc) return rc;
+  if (!phi_prev || !psi_t) return sd_set_err(ctx, SD_EARG, "null vector");
+  if (n != m->n_local) return sd_set_err(ctx, SD_EDIM, "vector length does not match the (local) basis dimension");
+  sd_epi_args ea; ea.a = a; ea.b = b; ea.c_re = c_re; ea.c_im = c_im; ea.prev = phi_prev; ea.accv = psi_t;
+  return sd_launch_apply(ctx, m, SD_C128, phi_next, phi_curr, SD_EPI_CHEB, ea);
+}
+
+static int apply_host(sd_ctx *ctx, const sd_model *m, int dtype, void *out, const void *psi, int64_t n, int epi,
+                      double a, double b) {
+  int rc = check_apply_args(ctx, m, dtype, out, psi, n);
+  if (rc) return rc;
+  if (m->nranks != 1) return sd_set_err(ctx, SD_EARG, "host-pointer applies need an unsharded model");
+  if (n != m->N) return sd_set_err(ctx, SD_EDIM, "vector length does not match the basis dimension");
+  const size_t bytes = (size_t)n * (dtype == SD_C128 ? 16 : 8);
+  TmpDev din(ctx), dout(ctx);
+  if ((rc = din.alloc(bytes)) || (rc = dout.alloc(bytes))) return rc;
+  SD_HIP(ctx, hipMemcpyAsync(din.p, psi, bytes, hipMemcpyHostToDevice, ctx->stream));
+  sd_epi_args ea; ea.a = a; ea.b = b;
+  rc = sd_launch_apply(ctx, m, dtype, dout.p, din.p, epi, ea);
+  if (rc) return rc;
+  SD_HIP(ctx, hipMemcpyAsync(out, dout.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SD_OK;
+}
+
+int sd_apply(sd_ctx *ctx, const sd_model *m, int dtype, void *out, const void *psi, int64_t n) {
+  return apply_host(ctx, m, dtype, out, psi, n, SD_EPI_PLAIN, 1.0, 0.0);
+}
+
+int sd_apply_rescaled(sd_ctx *ctx, const sd_model *m, int dtype, void *out, const void *psi, int64_t n, double a, double b) {
+  return apply_host(ctx, m, dtype, out, psi, n, SD_EPI_RESCALE, a, b);
+}
+
+int sd_szq_dev(sd_ctx *ctx, const sd_model *m, int dtype_in, const void *psi0, int64_t n, double q, void *phi) {
+  if (!ctx) return SD_EARG;
+  if (!m || !psi0 || !phi) return sd_set_err(ctx, SD_EARG, "null argument");
+  if (n != m->n_local) return sd_set_err(ctx, SD_EDIM, "vector length does not match the (local) basis dimension");
+  return sd_launch_szq(ctx, m, dtype_in, psi0, q, phi);
+}
+
+int sd_szq(sd_ctx *ctx, const sd_model *m, int dtype_in, const void *psi0, int64_t n, double q, void *phi) {
+  if (!ctx) return SD_EARG;
+  if (!m || !psi0 || !phi) return sd_set_err(ctx, SD_EARG, "null argument");
+  if (dtype_in != SD_F64 && dtype_in != SD_C128) return sd_set_err(ctx, SD_EARG, "bad dtype");
+  if (m->nranks != 1) return sd_set_err(ctx, SD_EARG, "host-pointer entry points need an unsharded model");
+  if (n != m->N) return sd_set_err(ctx, SD_EDIM, "vector length does not match the basis dimension");
+  const size_t bin = (size_t)n * (dtype_in == SD_C128 ? 16 : 8), bout = (size_t)n * 16;
+  TmpDev din(ctx), dout(ctx);
+  int rc;
+  if ((rc = din.alloc(bin)) || (rc = dout.alloc(bout))) return rc;
+  SD_HIP(ctx, hipMemcpyAsync(din.p, psi0, bin, hipMemcpyHostToDevice, ctx->stream));
+  rc = sd_launch_szq(ctx, m, dtype_in, din.p, q, dout.p);
+  if (rc) return rc;
+  SD_HIP(ctx, hipMemcpyAsync(phi, dout.p, bout, hipMemcpyDeviceToHost, ctx->stream));
+  SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SD_OK;
+}
+
+int sd_bench_apply_dev(sd_ctx *ctx, const sd_model *m, int dtype, void *buf_a, void *buf_b, int64_t n, int reps,
+                       float *ms_per_apply) {
+  int rc = check_apply_args(ctx, m, dtype, buf_a, buf_b, n);
+  if (rc) return rc;
+  if (n != m->n_local) return sd_set_err(ctx, SD_EDIM, "vector length does not match the (local) basis dimension");
+  if (reps < 1 || !ms_per_apply) return sd_set_err(ctx, SD_EARG, "bad reps");
+  sd_epi_args ea;
+  void *src = buf_a, *dst = buf_b;
+  SD_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  for (int r = 0; r < reps; ++r) {
+    rc = sd_launch_apply(ctx, m, dtype, dst, src, SD_EPI_PLAIN, ea);
+    if (rc) return rc;
+    void *t = src; src = dst; dst = t;
+  }
+  SD_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  SD_HIP(ctx, hipEventSynchronize(ctx->ev1));
+  float ms = 0.f;
+  SD_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+  *ms_per_apply = ms / reps;
+  return SD_OK;
+}
+
+int sd_fill_randn_dev(sd_ctx *ctx, void *x, int64_t n, uint64_t seed, uint64_t first) {
+  if (!ctx) return SD_EARG;
+  if (!x || n < 0) return sd_set_err(ctx, SD_EARG, "bad argument");
+  return sd_k_fill_randn(ctx, (double *)x, n, seed, first);
+}
+
+int sd_fill_randn_host(double *x, int64_t n, uint64_t seed, uint64_t first) {
+  if (!x || n < 0) return SD_EARG;
+  for (int64_t i = 0; i < n; ++i) x[i] = sd_randn_host(seed, first + (uint64_t)i);
+  return SD_OK;
+}
+
+}  // extern "C"

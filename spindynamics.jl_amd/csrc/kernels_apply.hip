@@ -1,0 +1,532 @@
+// H|psi> apply kernels for gfx950 (MI355X).  Replaces the reference's
+// Threads.@threads row loop of apply_H! (src/Hamiltonian.jl:211-273), the
+// separate rescale pass of apply_rescaled_H! (:286-301, fused here into the
+// store), and Sz_q_vector (:307-337).
+//
+// Two device paths:
+//  * k_apply_tiled   -- fixed-nup sector.  One workgroup per TILE (all rows
+//    sharing a prefix configuration of sites 1..p, see sd_internal.hpp).  The
+//    tile's psi is staged once in LDS; hops on bonds inside the suffix are LDS
+//    reads at idx +- C(LS-a-1,u) (no search, no hash); hops on prefix bonds
+//    are coalesced streams from another whole tile at the same in-tile offset;
+//    the straddling bond is a coalesced stream from half a tile.
+//  * k_apply_generic -- any model (full 2^L basis, L up to 63, arbitrary
+//    bonds): one row per thread, combinadic unrank / rank per hop.
+//
+// Per-row operation order follows the reference exactly (fields, zz in list
+// order, value = diag*psi[idx], then hops in list order, value += J*psi[idx'])
+// and the file is compiled with -ffp-contract=off, so a plain apply is
+// bit-identical to the CPU oracle.
+#include <hip/hip_runtime.h>
+
+#include "sd_internal.hpp"
+
+#define SD_BIN_STRIDE 17
+#define SD_ROWS_PER_THREAD 8
+
+namespace {
+
+template <int NC> struct VT;
+template <> struct VT<1> { using type = double; };
+template <> struct VT<2> { using type = double2; };
+
+__device__ __forceinline__ double vadd_mul(double acc, double J, double v) { return acc + J * v; }
+__device__ __forceinline__ double2 vadd_mul(double2 acc, double J, double2 v) {
+  return make_double2(acc.x + J * v.x, acc.y + J * v.y);
+}
+__device__ __forceinline__ double vscale(double d, double v) { return d * v; }
+__device__ __forceinline__ double2 vscale(double d, double2 v) { return make_double2(d * v.x, d * v.y); }
+
+__device__ __forceinline__ double sz_of(uint64_t bit) { return bit ? 0.5 : -0.5; }
+
+// diagonal matrix element for configuration s -- src/Hamiltonian.jl:226-241
+__device__ __forceinline__ double diag_of(const sd_dev_model &dm, uint64_t s) {
+  if (dm.diag_mode == 1) {
+    // uniform zz couplings whose partial sums are exact: sum of +-q == q*(n_par - n_anti)
+    int anti = 0, k0 = 0;
+    if (dm.n_zz_nn > 0) {
+      uint64_t x = (s ^ (s >> 1)) & (((uint64_t)1 << (dm.L - 1)) - 1);
+      anti = __popcll(x);
+      k0 = dm.n_zz_nn;
+    }
+    for (int k = k0; k < dm.n_zz; ++k)
+      anti += (int)(((s >> (dm.zz_i[k] - 1)) ^ (s >> (dm.zz_j[k] - 1))) & 1);
+    return dm.diag_q * (double)(dm.n_zz - 2 * anti);
+  }
+  double d = 0.0;
+  for (int i = 1; i <= dm.L; ++i) d += dm.field[i - 1] * sz_of((s >> (i - 1)) & 1);
+  for (int k = 0; k < dm.n_zz; ++k)
+    d += (dm.zz_J[k] * sz_of((s >> (dm.zz_i[k] - 1)) & 1)) * sz_of((s >> (dm.zz_j[k] - 1)) & 1);
+  return d;
+}
+
+__device__ __forceinline__ int64_t binom_g(const sd_dev_model &dm, int n, int k) {
+  return (k < 0 || k > n) ? 0 : dm.binom[n * (SD_MAX_L + 1) + k];
+}
+
+// combinadic unrank / rank in the reference order (generic path)
+__device__ __forceinline__ uint64_t unrank_g(const sd_dev_model &dm, int64_t idx) {
+  uint64_t s = 0;
+  int r = dm.nup;
+  for (int k = 1; k <= dm.L && r > 0; ++k) {
+    int64_t c = binom_g(dm, dm.L - k, r - 1);
+    if (idx < c) { s |= (uint64_t)1 << (k - 1); --r; }
+    else idx -= c;
+  }
+  return s;
+}
+__device__ __forceinline__ int64_t rank_g(const sd_dev_model &dm, uint64_t s) {
+  int64_t idx = 0;
+  int r = dm.nup;
+  for (int k = 1; k <= dm.L && r > 0; ++k) {
+    if ((s >> (k - 1)) & 1) --r;
+    else idx += binom_g(dm, dm.L - k, r - 1);
+  }
+  return idx;
+}
+
+// ---- epilogue: what is stored for row `row` given acc = (H psi)[row] ----
+struct EpiSums { double s0, s1; };
+
+template <int NC>
+__device__ __forceinline__ void epilogue(int epi, const sd_epi_args &ea, int64_t row, typename VT<NC>::type acc,
+                                         typename VT<NC>::type own, double *out, EpiSums &sums);
+
+template <>
+__device__ __forceinline__ void epilogue<1>(int epi, const sd_epi_args &ea, int64_t row, double acc, double own,
+                                            double *out, EpiSums &sums) {
+  switch (epi) {
+    case SD_EPI_PLAIN:
+      out[row] = ea.negate ? -acc : acc;
+      break;
+    case SD_EPI_DOT: {
+      double o = ea.negate ? -acc : acc;
+      out[row] = o;
+      sums.s0 += own * o;
+    } break;
+    case SD_EPI_RESCALE:
+      out[row] = (acc - ea.b * own) / ea.a;
+      break;
+    case SD_EPI_RESCALE_DOT: {
+      double o = (acc - ea.b * own) / ea.a;
+      out[row] = o;
+      double ph = ((const double *)ea.phi)[row];
+      sums.s0 += ph * o;
+      sums.s1 += o * o;
+    } break;
+    case SD_EPI_KPM: {
+      double o = 2.0 * ((acc - ea.b * own) / ea.a) - ((const double *)ea.prev)[row];
+      out[row] = o;
+      double ph = ((const double *)ea.phi)[row];
+      sums.s0 += ph * o;
+      sums.s1 += o * o;
+    } break;
+    default: {  // SD_EPI_CHEB on real vectors: real accumulate with real coefficient
+      double o = 2.0 * ((acc - ea.b * own) / ea.a) - ((const double *)ea.prev)[row];
+      out[row] = o;
+      double *pt = (double *)ea.accv;
+      pt[row] += ea.c_re * o;
+    } break;
+  }
+}
+
+template <>
+__device__ __forceinline__ void epilogue<2>(int epi, const sd_epi_args &ea, int64_t row, double2 acc, double2 own,
+                                            double *out, EpiSums &sums) {
+  double2 *o2 = (double2 *)out;
+  switch (epi) {
+    case SD_EPI_PLAIN:
+      o2[row] = ea.negate ? make_double2(-acc.x, -acc.y) : acc;
+      break;
+    case SD_EPI_DOT: {
+      double2 o = ea.negate ? make_double2(-acc.x, -acc.y) : acc;
+      o2[row] = o;
+      sums.s0 += own.x * o.x + own.y * o.y;   // conj(own) * o
+      sums.s1 += own.x * o.y - own.y * o.x;
+    } break;
+    case SD_EPI_RESCALE:
+      o2[row] = make_double2((acc.x - ea.b * own.x) / ea.a, (acc.y - ea.b * own.y) / ea.a);
+      break;
+    case SD_EPI_RESCALE_DOT: {
+      double2 o = make_double2((acc.x - ea.b * own.x) / ea.a, (acc.y - ea.b * own.y) / ea.a);
+      o2[row] = o;
+      double2 ph = ((const double2 *)ea.phi)[row];
+      sums.s0 += ph.x * o.x + ph.y * o.y;     // Re <phi|o>
+      sums.s1 += o.x * o.x + o.y * o.y;
+    } break;
+    case SD_EPI_KPM: {
+      double2 pv = ((const double2 *)ea.prev)[row];
+      double2 o = make_double2(2.0 * ((acc.x - ea.b * own.x) / ea.a) - pv.x,
+                               2.0 * ((acc.y - ea.b * own.y) / ea.a) - pv.y);
+      o2[row] = o;
+      double2 ph = ((const double2 *)ea.phi)[row];
+      sums.s0 += ph.x * o.x + ph.y * o.y;
+      sums.s1 += o.x * o.x + o.y * o.y;
+    } break;
+    default: {  // SD_EPI_CHEB  (src/TimeEvolution/Chebyshev.jl:112-117)
+      double2 pv = ((const double2 *)ea.prev)[row];
+      double2 o = make_double2(2.0 * ((acc.x - ea.b * own.x) / ea.a) - pv.x,
+                               2.0 * ((acc.y - ea.b * own.y) / ea.a) - pv.y);
+      o2[row] = o;
+      double2 *pt = (double2 *)ea.accv;
+      double2 t = pt[row];
+      t.x += ea.c_re * o.x - ea.c_im * o.y;
+      t.y += ea.c_re * o.y + ea.c_im * o.x;
+      pt[row] = t;
+    } break;
+  }
+}
+
+// deterministic block reduction of two doubles; result valid in thread 0
+__device__ __forceinline__ void block_reduce2(double &a, double &b, double *red /* >= 2*16 doubles LDS */) {
+  for (int off = 32; off > 0; off >>= 1) {
+    a += __shfl_down(a, off, 64);
+    b += __shfl_down(b, off, 64);
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  if (lane == 0) { red[2 * wv] = a; red[2 * wv + 1] = b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double x = 0.0, y = 0.0;
+    for (int w = 0; w < nw; ++w) { x += red[2 * w]; y += red[2 * w + 1]; }
+    a = x; b = y;
+  }
+}
+
+__device__ __forceinline__ bool epi_has_sums(int epi) {
+  return epi == SD_EPI_DOT || epi == SD_EPI_KPM || epi == SD_EPI_RESCALE_DOT;
+}
+
+// =====================================================================
+// tiled kernel
+// =====================================================================
+template <int NC>
+__global__ __launch_bounds__(1024) void k_apply_tiled(sd_dev_model dm, double *__restrict__ out_,
+                                                      const double *__restrict__ psi_, int epi, sd_epi_args ea,
+                                                      double *__restrict__ partials, int max_len) {
+  using V = typename VT<NC>::type;
+  constexpr int R = SD_ROWS_PER_THREAD;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  V *tile = reinterpret_cast<V *>(smem);
+  int *lbin = reinterpret_cast<int *>(smem + (size_t)max_len * sizeof(V));
+  double *red = reinterpret_cast<double *>(lbin + 16 * SD_BIN_STRIDE);
+
+  const V *__restrict__ psi = reinterpret_cast<const V *>(psi_);
+  const int tid = threadIdx.x, BS = blockDim.x;
+  const int tix = blockIdx.x;
+  const uint32_t P = dm.tile_prefix[tix];
+  const int64_t base = dm.tile_base[tix];
+  const int p = dm.p, LS = dm.LS;
+  const int t2 = dm.nup - __popc(P);
+  const int len = (int)binom_g(dm, LS, t2);
+  const int nU = (int)binom_g(dm, LS - 1, t2 - 1);  // rows whose first suffix site is up
+  const uint16_t *__restrict__ sufS = dm.suf_states + dm.suf_off[t2];
+
+  // ---- stage: own rows -> registers + LDS, suffix configurations, binomials ----
+  uint32_t sig[R];
+  int irow[R];
+  {
+    V own[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int i = tid + r * BS;
+      const int ic = i < len ? i : len - 1;
+      irow[r] = ic;
+      own[r] = psi[base + ic];
+      sig[r] = sufS[ic];
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      if (tid + r * BS < len) tile[irow[r]] = own[r];
+  }
+  for (int k = tid; k < 16 * SD_BIN_STRIDE; k += BS) {
+    int n = k / SD_BIN_STRIDE, kk = k - n * SD_BIN_STRIDE;
+    lbin[k] = (int)binom_g(dm, n, kk);
+  }
+  __syncthreads();
+
+  // ---- diagonal ----
+  V acc[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const uint64_t s = (uint64_t)P | ((uint64_t)sig[r] << p);
+    acc[r] = vscale(diag_of(dm, s), tile[irow[r]]);
+  }
+
+  const int nn = dm.nn_hops;
+  if (nn > 0) {
+    // ---- bonds inside the prefix: whole-tile streams (wave-uniform control flow) ----
+    for (int b = 1; b <= p - 1; ++b) {
+      if (((P >> (b - 1)) ^ (P >> b)) & 1u) {
+        const int64_t qb = dm.addr[P ^ (3u << (b - 1))];
+        const double J = dm.hop_J[b - 1];
+        const V *__restrict__ src = psi + qb;
+        V v[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) v[r] = src[irow[r]];
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = vadd_mul(acc[r], J, v[r]);
+      }
+    }
+    // ---- the bond straddling prefix | suffix: half-tile stream ----
+    if (p >= 1) {
+      const uint32_t bitp = (P >> (p - 1)) & 1u;
+      const uint32_t Q = P ^ (1u << (p - 1));
+      const int t2q = dm.nup - __popc(Q);
+      if (t2q >= 0 && t2q <= LS) {
+        const int64_t qb = dm.addr[Q];
+        const double J = dm.hop_J[p - 1];
+        const V *__restrict__ src = psi + qb;
+        // bitp = 1: our rows with first suffix site down (i >= nU) <-> partner rows i - nU
+        // bitp = 0: our rows with first suffix site up   (i <  nU) <-> partner rows nUq + i
+        const int nUq = (int)binom_g(dm, LS - 1, t2q - 1);
+        V v[R];
+        bool fl[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int i = irow[r];
+          fl[r] = bitp ? (i >= nU) : (i < nU);
+          const int ip = bitp ? (i - nU) : (nUq + i);
+          v[r] = src[fl[r] ? ip : 0];
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+          if (fl[r]) acc[r] = vadd_mul(acc[r], J, v[r]);
+      }
+    }
+    // ---- bonds inside the suffix: LDS reads at idx +- C(LS-a-1, u) ----
+    for (int a = 1; a <= LS - 1; ++a) {
+      const double J = dm.hop_J[p + a - 1];
+      const int *brow = lbin + (LS - a - 1) * SD_BIN_STRIDE;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const uint32_t sg = sig[r];
+        const uint32_t ba = (sg >> (a - 1)) & 1u, bb = (sg >> a) & 1u;
+        if (ba != bb) {
+          const int u = __popc(sg >> (a + 1));
+          const int d = brow[u];
+          const int ip = ba ? irow[r] + d : irow[r] - d;
+          acc[r] = vadd_mul(acc[r], J, tile[ip]);
+        }
+      }
+    }
+  }
+  // ---- remaining (general) bonds: rank through the tile tables ----
+  if (nn < dm.n_hop) {
+    const uint64_t pmask = ((uint64_t)1 << p) - 1;
+    for (int h = nn; h < dm.n_hop; ++h) {
+      const int bi = dm.hop_i[h] - 1, bj = dm.hop_j[h] - 1;
+      const double J = dm.hop_J[h];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const uint64_t s = (uint64_t)P | ((uint64_t)sig[r] << p);
+        if (((s >> bi) ^ (s >> bj)) & 1) {
+          const uint64_t s2 = s ^ ((uint64_t)1 << bi) ^ ((uint64_t)1 << bj);
+          const int64_t idx = dm.addr[(uint32_t)(s2 & pmask)] + dm.suf_rank[(uint32_t)(s2 >> p)];
+          acc[r] = vadd_mul(acc[r], J, psi[idx]);
+        }
+      }
+    }
+  }
+
+  // ---- epilogue + store ----
+  EpiSums sums{0.0, 0.0};
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int i = tid + r * BS;
+    if (i < len) epilogue<NC>(epi, ea, base + i, acc[r], tile[i], out_, sums);
+  }
+  if (epi_has_sums(epi)) {
+    double a = sums.s0, b = sums.s1;
+    block_reduce2(a, b, red);
+    if (tid == 0) { partials[2 * (size_t)tix] = a; partials[2 * (size_t)tix + 1] = b; }
+  }
+}
+
+// =====================================================================
+// generic kernel: one row per thread, grid-stride
+// =====================================================================
+template <int NC>
+__global__ __launch_bounds__(256) void k_apply_generic(sd_dev_model dm, double *__restrict__ out_,
+                                                       const double *__restrict__ psi_, int epi, sd_epi_args ea,
+                                                       double *__restrict__ partials) {
+  using V = typename VT<NC>::type;
+  __shared__ double red[32];
+  const V *__restrict__ psi = reinterpret_cast<const V *>(psi_);
+  const bool full = dm.nup < 0;
+  EpiSums sums{0.0, 0.0};
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < dm.N; idx += stride) {
+    const uint64_t s = full ? (uint64_t)idx : unrank_g(dm, idx);
+    const V own = psi[idx];
+    V acc = vscale(diag_of(dm, s), own);
+    for (int h = 0; h < dm.n_hop; ++h) {
+      const int bi = dm.hop_i[h] - 1, bj = dm.hop_j[h] - 1;
+      if (((s >> bi) ^ (s >> bj)) & 1) {
+        const uint64_t s2 = s ^ ((uint64_t)1 << bi) ^ ((uint64_t)1 << bj);
+        const int64_t nidx = full ? (int64_t)s2 : rank_g(dm, s2);
+        acc = vadd_mul(acc, dm.hop_J[h], psi[nidx]);
+      }
+    }
+    epilogue<NC>(epi, ea, idx, acc, own, out_, sums);
+  }
+  if (epi_has_sums(epi)) {
+    double a = sums.s0, b = sums.s1;
+    block_reduce2(a, b, red);
+    if (threadIdx.x == 0) { partials[2 * (size_t)blockIdx.x] = a; partials[2 * (size_t)blockIdx.x + 1] = b; }
+  }
+}
+
+// fixed-order reduction of the per-block partial pairs -> scalars[0..1]
+__global__ __launch_bounds__(1024) void k_reduce_pairs(const double *__restrict__ partials, int64_t n,
+                                                       double *__restrict__ scalars) {
+  __shared__ double red[32];
+  double a = 0.0, b = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) { a += partials[2 * i]; b += partials[2 * i + 1]; }
+  block_reduce2(a, b, red);
+  if (threadIdx.x == 0) { scalars[0] = a; scalars[1] = b; }
+}
+
+// =====================================================================
+// Sz_q_vector  (src/Hamiltonian.jl:307-337)
+// =====================================================================
+struct SzqPhases { double re[SD_MAX_L + 1], im[SD_MAX_L + 1]; };
+
+template <int NCIN>
+__device__ __forceinline__ void szq_row(const sd_dev_model &dm, const SzqPhases &ph, double normfact, uint64_t s,
+                                        const double *__restrict__ psi0, int64_t row, double2 *__restrict__ phi) {
+  double sr = 0.0, si = 0.0;
+  for (int r = 0; r < dm.L; ++r) {
+    const double z = sz_of((s >> r) & 1);
+    sr += ph.re[r] * z;
+    si += ph.im[r] * z;
+  }
+  const double ar = normfact * sr, ai = normfact * si;
+  double xr, xi;
+  if (NCIN == 2) { xr = psi0[2 * row]; xi = psi0[2 * row + 1]; }
+  else { xr = psi0[row]; xi = 0.0; }
+  phi[row] = make_double2(ar * xr - ai * xi, ar * xi + ai * xr);
+}
+
+template <int NCIN>
+__global__ __launch_bounds__(256) void k_szq_tiled(sd_dev_model dm, SzqPhases ph, double normfact,
+                                                   const double *__restrict__ psi0, double2 *__restrict__ phi) {
+  const int tix = blockIdx.x;
+  const uint32_t P = dm.tile_prefix[tix];
+  const int64_t base = dm.tile_base[tix];
+  const int t2 = dm.nup - __popc(P);
+  const int len = (int)binom_g(dm, dm.LS, t2);
+  const uint16_t *__restrict__ sufS = dm.suf_states + dm.suf_off[t2];
+  for (int i = threadIdx.x; i < len; i += blockDim.x) {
+    const uint64_t s = (uint64_t)P | ((uint64_t)sufS[i] << dm.p);
+    szq_row<NCIN>(dm, ph, normfact, s, psi0, base + i, phi);
+  }
+}
+
+template <int NCIN>
+__global__ __launch_bounds__(256) void k_szq_generic(sd_dev_model dm, SzqPhases ph, double normfact,
+                                                     const double *__restrict__ psi0, double2 *__restrict__ phi) {
+  const bool full = dm.nup < 0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < dm.N; idx += stride) {
+    const uint64_t s = full ? (uint64_t)idx : unrank_g(dm, idx);
+    szq_row<NCIN>(dm, ph, normfact, s, psi0, idx, phi);
+  }
+}
+
+int ensure_partials(sd_ctx *ctx, size_t doubles) {
+  if (ctx->partials_cap >= doubles) return SD_OK;
+  if (ctx->d_partials) (void)hipFree(ctx->d_partials);
+  ctx->d_partials = nullptr; ctx->partials_cap = 0;
+  SD_HIP(ctx, hipMalloc((void **)&ctx->d_partials, doubles * sizeof(double)));
+  ctx->partials_cap = doubles;
+  return SD_OK;
+}
+
+int block_for_len(int max_len) {
+  int bs = 64;
+  while (bs < 1024 && bs * SD_ROWS_PER_THREAD < max_len) bs <<= 1;
+  return bs;
+}
+
+}  // namespace
+
+int sd_launch_apply(sd_ctx *ctx, const sd_model *m, int dtype, void *out, const void *psi, int epi,
+                    const sd_epi_args &ea) {
+  if (!m->dev_ready) return sd_set_err(ctx, SD_EARG, "model has no device tables (created without a context)");
+  if (dtype != SD_F64 && dtype != SD_C128) return sd_set_err(ctx, SD_EARG, "dtype must be SD_F64 or SD_C128");
+  const bool sums = (epi == SD_EPI_DOT || epi == SD_EPI_KPM || epi == SD_EPI_RESCALE_DOT);
+  const sd_dev_model &dm = m->dm;
+  if (dm.n_local == 0) return SD_OK;
+  if (m->p >= 0) {
+    const int nt = dm.n_tiles;
+    if (sums) { int rc = ensure_partials(ctx, 2 * (size_t)nt); if (rc) return rc; }
+    const int max_len = m->max_tile_len;
+    if (max_len > 1024 * SD_ROWS_PER_THREAD) return sd_set_err(ctx, SD_EINTERNAL, "tile longer than a workgroup can hold");
+    const int bs = block_for_len(max_len);
+    const size_t esz = dtype == SD_C128 ? 16 : 8;
+    const size_t shmem = (size_t)max_len * esz + 16 * SD_BIN_STRIDE * sizeof(int) + 32 * sizeof(double) + 16;
+    if (dtype == SD_C128) {
+      if (shmem > 48 * 1024)
+        SD_HIP(ctx, hipFuncSetAttribute((const void *)k_apply_tiled<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+      hipLaunchKernelGGL(k_apply_tiled<2>, dim3(nt), dim3(bs), shmem, ctx->stream, dm, (double *)out,
+                         (const double *)psi, epi, ea, ctx->d_partials, max_len);
+    } else {
+      if (shmem > 48 * 1024)
+        SD_HIP(ctx, hipFuncSetAttribute((const void *)k_apply_tiled<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+      hipLaunchKernelGGL(k_apply_tiled<1>, dim3(nt), dim3(bs), shmem, ctx->stream, dm, (double *)out,
+                         (const double *)psi, epi, ea, ctx->d_partials, max_len);
+    }
+    SD_HIP(ctx, hipGetLastError());
+    if (sums) {
+      hipLaunchKernelGGL(k_reduce_pairs, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_partials, (int64_t)nt, ctx->d_scalars);
+      SD_HIP(ctx, hipGetLastError());
+    }
+  } else {
+    int64_t nb = (dm.N + 255) / 256;
+    if (nb > 8192) nb = 8192;
+    if (sums) { int rc = ensure_partials(ctx, 2 * (size_t)nb); if (rc) return rc; }
+    if (dtype == SD_C128)
+      hipLaunchKernelGGL(k_apply_generic<2>, dim3((unsigned)nb), dim3(256), 0, ctx->stream, dm, (double *)out,
+                         (const double *)psi, epi, ea, ctx->d_partials);
+    else
+      hipLaunchKernelGGL(k_apply_generic<1>, dim3((unsigned)nb), dim3(256), 0, ctx->stream, dm, (double *)out,
+                         (const double *)psi, epi, ea, ctx->d_partials);
+    SD_HIP(ctx, hipGetLastError());
+    if (sums) {
+      hipLaunchKernelGGL(k_reduce_pairs, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_partials, nb, ctx->d_scalars);
+      SD_HIP(ctx, hipGetLastError());
+    }
+  }
+  return SD_OK;
+}
+
+int sd_launch_szq(sd_ctx *ctx, const sd_model *m, int dtype_in, const void *psi0, double q, void *phi) {
+  if (!m->dev_ready) return sd_set_err(ctx, SD_EARG, "model has no device tables (created without a context)");
+  if (dtype_in != SD_F64 && dtype_in != SD_C128) return sd_set_err(ctx, SD_EARG, "dtype must be SD_F64 or SD_C128");
+  const sd_dev_model &dm = m->dm;
+  if (dm.n_local == 0) return SD_OK;
+  SzqPhases ph;
+  // phases = exp.(im*q*(0:L-1))  (src/Hamiltonian.jl:317), computed on the host in double
+  for (int r = 0; r < dm.L; ++r) { double x = q * (double)r; ph.re[r] = cos(x); ph.im[r] = sin(x); }
+  const double normfact = 1.0 / sqrt((double)dm.L);
+  if (m->p >= 0) {
+    if (dtype_in == SD_C128)
+      hipLaunchKernelGGL(k_szq_tiled<2>, dim3(dm.n_tiles), dim3(256), 0, ctx->stream, dm, ph, normfact,
+                         (const double *)psi0, (double2 *)phi);
+    else
+      hipLaunchKernelGGL(k_szq_tiled<1>, dim3(dm.n_tiles), dim3(256), 0, ctx->stream, dm, ph, normfact,
+                         (const double *)psi0, (double2 *)phi);
+  } else {
+    int64_t nb = (dm.N + 255) / 256;
+    if (nb > 8192) nb = 8192;
+    if (dtype_in == SD_C128)
+      hipLaunchKernelGGL(k_szq_generic<2>, dim3((unsigned)nb), dim3(256), 0, ctx->stream, dm, ph, normfact,
+                         (const double *)psi0, (double2 *)phi);
+    else
+      hipLaunchKernelGGL(k_szq_generic<1>, dim3((unsigned)nb), dim3(256), 0, ctx->stream, dm, ph, normfact,
+                         (const double *)psi0, (double2 *)phi);
+  }
+  SD_HIP(ctx, hipGetLastError());
+  return SD_OK;
+}

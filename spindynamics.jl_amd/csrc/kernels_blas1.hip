@@ -1,0 +1,252 @@
+// BLAS-1 style device kernels used by the on-device recursions (the reference
+// uses LinearAlgebra.dot / norm / broadcast on host vectors: src/Lanczos.jl,
+// src/TimeEvolution/Krylov.jl, src/TimeEvolution/Chebyshev.jl, src/KPM_Sqw.jl).
+// All are single-pass HBM streams with 16-byte accesses; reductions are
+// two-stage with a fixed order (deterministic run to run).
+#include <hip/hip_runtime.h>
+
+#include "sd_internal.hpp"
+
+namespace {
+
+constexpr int RED_BLOCKS = 2048;
+constexpr int BS = 256;
+
+__device__ __forceinline__ void block_reduce2(double &a, double &b, double *red) {
+  for (int off = 32; off > 0; off >>= 1) {
+    a += __shfl_down(a, off, 64);
+    b += __shfl_down(b, off, 64);
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  if (lane == 0) { red[2 * wv] = a; red[2 * wv + 1] = b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double x = 0.0, y = 0.0;
+    for (int w = 0; w < nw; ++w) { x += red[2 * w]; y += red[2 * w + 1]; }
+    a = x; b = y;
+  }
+}
+
+// conj(x).y for complex (nc=2) or x.y for real (nc=1); n2 = number of double2 elements when vectorised
+template <int NC>
+__global__ __launch_bounds__(BS) void k_dot(const double *__restrict__ x, const double *__restrict__ y, int64_t N,
+                                            double *__restrict__ partials) {
+  __shared__ double red[32];
+  double a = 0.0, b = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  if (NC == 2) {
+    const double2 *x2 = (const double2 *)x, *y2 = (const double2 *)y;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += stride) {
+      double2 u = x2[i], v = y2[i];
+      a += u.x * v.x + u.y * v.y;
+      b += u.x * v.y - u.y * v.x;
+    }
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += stride) a += x[i] * y[i];
+  }
+  block_reduce2(a, b, red);
+  if (threadIdx.x == 0) { partials[2 * blockIdx.x] = a; partials[2 * blockIdx.x + 1] = b; }
+}
+
+__global__ __launch_bounds__(BS) void k_nrm2sq(const double *__restrict__ x, int64_t n, double *__restrict__ partials) {
+  __shared__ double red[32];
+  double a = 0.0, b = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) { double v = x[i]; a += v * v; }
+  block_reduce2(a, b, red);
+  if (threadIdx.x == 0) { partials[2 * blockIdx.x] = a; partials[2 * blockIdx.x + 1] = b; }
+}
+
+__global__ __launch_bounds__(1024) void k_reduce_to(const double *__restrict__ partials, int n, double *__restrict__ dst) {
+  __shared__ double red[32];
+  double a = 0.0, b = 0.0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) { a += partials[2 * i]; b += partials[2 * i + 1]; }
+  block_reduce2(a, b, red);
+  if (threadIdx.x == 0) { dst[0] = a; dst[1] = b; }
+}
+
+enum { OP_SCALE_DIV, OP_NEG, OP_SUB_AXPBY, OP_SUB_AXPBY1, OP_SUB2, OP_SUB2_1 };
+
+template <int OP>
+__global__ __launch_bounds__(BS) void k_ew(double *__restrict__ w, const double *__restrict__ v,
+                                           const double *__restrict__ u, int64_t n, double a, double b) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    if (OP == OP_SCALE_DIV) w[i] = v[i] / a;
+    else if (OP == OP_NEG) w[i] = -w[i];
+    else if (OP == OP_SUB_AXPBY) w[i] = w[i] - (a * v[i] + b * u[i]);
+    else if (OP == OP_SUB_AXPBY1) w[i] = w[i] - a * v[i];
+    else if (OP == OP_SUB2) w[i] = (w[i] - a * v[i]) - b * u[i];
+    else if (OP == OP_SUB2_1) w[i] = w[i] - a * v[i];
+  }
+}
+
+// w -= alpha*v (complex alpha) ; y += alpha*x
+template <int SIGN>
+__global__ __launch_bounds__(BS) void k_caxpy(double2 *__restrict__ w, const double2 *__restrict__ v, int64_t N,
+                                              double ar, double ai) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += stride) {
+    double2 x = v[i], y = w[i];
+    const double tr = ar * x.x - ai * x.y, ti = ar * x.y + ai * x.x;
+    if (SIGN < 0) { y.x -= tr; y.y -= ti; } else { y.x += tr; y.y += ti; }
+    w[i] = y;
+  }
+}
+
+__global__ __launch_bounds__(BS) void k_cheb_init(double2 *__restrict__ y, const double2 *__restrict__ x0,
+                                                  const double2 *__restrict__ x1, int64_t N, double c0r, double c0i,
+                                                  double c1r, double c1i, int have1) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += stride) {
+    // psi_t = 0; psi_t += c[1]*phi_prev; psi_t += c[2]*phi_curr   (src/TimeEvolution/Chebyshev.jl:96-102)
+    double tr = 0.0, ti = 0.0;
+    double2 a = x0[i];
+    tr += c0r * a.x - c0i * a.y; ti += c0r * a.y + c0i * a.x;
+    if (have1) { double2 b = x1[i]; tr += c1r * b.x - c1i * b.y; ti += c1r * b.y + c1i * b.x; }
+    y[i] = make_double2(tr, ti);
+  }
+}
+
+__global__ __launch_bounds__(BS) void k_promote(double2 *__restrict__ y, const double *__restrict__ x, int nc, int64_t N) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += stride)
+    y[i] = nc == 2 ? make_double2(x[2 * i], x[2 * i + 1]) : make_double2(x[i], 0.0);
+}
+
+#define SD_GEMV_MAXC 256
+struct GemvCoef { double c[SD_GEMV_MAXC]; };
+__global__ __launch_bounds__(BS) void k_gemv_cols(double *__restrict__ y, const double *__restrict__ V, int64_t N,
+                                                  int k0, int ncols, GemvCoef coef, int first) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += stride) {
+    double s = first ? 0.0 : y[i];
+    for (int k = 0; k < ncols; ++k) s += V[i + N * (int64_t)(k0 + k)] * coef.c[k];
+    y[i] = s;
+  }
+}
+
+// counter-based N(0,1): element k of stream `seed` = Box-Muller on two uniforms hashed from (seed, k)
+__host__ __device__ inline uint64_t mix64(uint64_t z) {
+  z += 0x9E3779B97F4A7C15ULL;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  return z ^ (z >> 31);
+}
+__host__ __device__ inline double randn_at(uint64_t seed, uint64_t k) {
+  const uint64_t h1 = mix64(seed ^ mix64(2 * k)), h2 = mix64(seed ^ mix64(2 * k + 1));
+  const double u1 = ((double)(h1 >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+  const double u2 = ((double)(h2 >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+  return sqrt(-2.0 * log(u1)) * cos(6.283185307179586476925286766559 * u2);
+}
+__global__ __launch_bounds__(BS) void k_fill_randn(double *__restrict__ x, int64_t n, uint64_t seed, uint64_t first) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) x[i] = randn_at(seed, first + (uint64_t)i);
+}
+
+inline unsigned grid_for(int64_t n) {
+  int64_t nb = (n + BS - 1) / BS;
+  if (nb > 16384) nb = 16384;
+  if (nb < 1) nb = 1;
+  return (unsigned)nb;
+}
+
+int ensure_partials(sd_ctx *ctx, size_t doubles) {
+  if (ctx->partials_cap >= doubles) return SD_OK;
+  if (ctx->d_partials) (void)hipFree(ctx->d_partials);
+  ctx->d_partials = nullptr; ctx->partials_cap = 0;
+  SD_HIP(ctx, hipMalloc((void **)&ctx->d_partials, doubles * sizeof(double)));
+  ctx->partials_cap = doubles;
+  return SD_OK;
+}
+
+}  // namespace
+
+double sd_randn_host(uint64_t seed, uint64_t k) { return randn_at(seed, k); }
+
+int sd_k_dot(sd_ctx *ctx, int nc, const double *x, const double *y, int64_t N, int slot) {
+  int rc = ensure_partials(ctx, 2 * RED_BLOCKS); if (rc) return rc;
+  int nb = (int)std::min<int64_t>(RED_BLOCKS, std::max<int64_t>(1, (N + BS - 1) / BS));
+  if (nc == 2) hipLaunchKernelGGL(k_dot<2>, dim3(nb), dim3(BS), 0, ctx->stream, x, y, N, ctx->d_partials);
+  else hipLaunchKernelGGL(k_dot<1>, dim3(nb), dim3(BS), 0, ctx->stream, x, y, N, ctx->d_partials);
+  hipLaunchKernelGGL(k_reduce_to, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_partials, nb, ctx->d_scalars + slot);
+  SD_HIP(ctx, hipGetLastError());
+  return SD_OK;
+}
+
+int sd_k_nrm2sq(sd_ctx *ctx, const double *x, int64_t n, int slot) {
+  int rc = ensure_partials(ctx, 2 * RED_BLOCKS); if (rc) return rc;
+  int nb = (int)std::min<int64_t>(RED_BLOCKS, std::max<int64_t>(1, (n + BS - 1) / BS));
+  hipLaunchKernelGGL(k_nrm2sq, dim3(nb), dim3(BS), 0, ctx->stream, x, n, ctx->d_partials);
+  hipLaunchKernelGGL(k_reduce_to, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_partials, nb, ctx->d_scalars + slot);
+  SD_HIP(ctx, hipGetLastError());
+  return SD_OK;
+}
+
+int sd_read_scalars(sd_ctx *ctx, int slot, int count, double *out) {
+  SD_HIP(ctx, hipMemcpyAsync(ctx->h_scalars + slot, ctx->d_scalars + slot, sizeof(double) * count,
+                             hipMemcpyDeviceToHost, ctx->stream));
+  SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (int i = 0; i < count; ++i) out[i] = ctx->h_scalars[slot + i];
+  return SD_OK;
+}
+
+int sd_k_scale_div(sd_ctx *ctx, double *y, const double *x, int64_t n, double d) {
+  hipLaunchKernelGGL(k_ew<OP_SCALE_DIV>, dim3(grid_for(n)), dim3(BS), 0, ctx->stream, y, x, (const double *)nullptr, n, d, 0.0);
+  SD_HIP(ctx, hipGetLastError());
+  return SD_OK;
+}
+int sd_k_neg(sd_ctx *ctx, double *x, int64_t n) {
+  hipLaunchKernelGGL(k_ew<OP_NEG>, dim3(grid_for(n)), dim3(BS), 0, ctx->stream, x, (const double *)nullptr, (const double *)nullptr, n, 0.0, 0.0);
+  SD_HIP(ctx, hipGetLastError());
+  return SD_OK;
+}
+int sd_k_sub_axpby(sd_ctx *ctx, double *w, const double *v, const double *u, int64_t n, double a, double b) {
+  if (u) hipLaunchKernelGGL(k_ew<OP_SUB_AXPBY>, dim3(grid_for(n)), dim3(BS), 0, ctx->stream, w, v, u, n, a, b);
+  else hipLaunchKernelGGL(k_ew<OP_SUB_AXPBY1>, dim3(grid_for(n)), dim3(BS), 0, ctx->stream, w, v, u, n, a, b);
+  SD_HIP(ctx, hipGetLastError());
+  return SD_OK;
+}
+int sd_k_sub2(sd_ctx *ctx, double *w, const double *v, const double *u, int64_t n, double a, double b) {
+  if (u) hipLaunchKernelGGL(k_ew<OP_SUB2>, dim3(grid_for(n)), dim3(BS), 0, ctx->stream, w, v, u, n, a, b);
+  else hipLaunchKernelGGL(k_ew<OP_SUB2_1>, dim3(grid_for(n)), dim3(BS), 0, ctx->stream, w, v, u, n, a, b);
+  SD_HIP(ctx, hipGetLastError());
+  return SD_OK;
+}
+int sd_k_csub(sd_ctx *ctx, double *w, const double *v, int64_t N, double ar, double ai) {
+  hipLaunchKernelGGL(k_caxpy<-1>, dim3(grid_for(N)), dim3(BS), 0, ctx->stream, (double2 *)w, (const double2 *)v, N, ar, ai);
+  SD_HIP(ctx, hipGetLastError());
+  return SD_OK;
+}
+int sd_k_cacc(sd_ctx *ctx, double *y, const double *x, int64_t N, double ar, double ai) {
+  hipLaunchKernelGGL(k_caxpy<1>, dim3(grid_for(N)), dim3(BS), 0, ctx->stream, (double2 *)y, (const double2 *)x, N, ar, ai);
+  SD_HIP(ctx, hipGetLastError());
+  return SD_OK;
+}
+int sd_k_cheb_init(sd_ctx *ctx, double *y, const double *x0, const double *x1, int64_t N, double c0r, double c0i,
+                   double c1r, double c1i, int have1) {
+  hipLaunchKernelGGL(k_cheb_init, dim3(grid_for(N)), dim3(BS), 0, ctx->stream, (double2 *)y, (const double2 *)x0,
+                     (const double2 *)x1, N, c0r, c0i, c1r, c1i, have1);
+  SD_HIP(ctx, hipGetLastError());
+  return SD_OK;
+}
+int sd_k_promote(sd_ctx *ctx, double *yc, const double *x, int nc_in, int64_t N) {
+  hipLaunchKernelGGL(k_promote, dim3(grid_for(N)), dim3(BS), 0, ctx->stream, (double2 *)yc, x, nc_in, N);
+  SD_HIP(ctx, hipGetLastError());
+  return SD_OK;
+}
+int sd_k_gemv_cols(sd_ctx *ctx, double *y, const double *V, int64_t N, int ncols, const double *coef_host) {
+  for (int k0 = 0; k0 < ncols; k0 += SD_GEMV_MAXC) {
+    GemvCoef c;
+    int nc = std::min(SD_GEMV_MAXC, ncols - k0);
+    for (int k = 0; k < nc; ++k) c.c[k] = coef_host[k0 + k];
+    hipLaunchKernelGGL(k_gemv_cols, dim3(grid_for(N)), dim3(BS), 0, ctx->stream, y, V, N, k0, nc, c, k0 == 0 ? 1 : 0);
+  }
+  SD_HIP(ctx, hipGetLastError());
+  return SD_OK;
+}
+int sd_k_fill_randn(sd_ctx *ctx, double *x, int64_t n, uint64_t seed, uint64_t first) {
+  hipLaunchKernelGGL(k_fill_randn, dim3(grid_for(n)), dim3(BS), 0, ctx->stream, x, n, seed, first);
+  SD_HIP(ctx, hipGetLastError());
+  return SD_OK;
+}

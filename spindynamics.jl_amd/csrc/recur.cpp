@@ -1,0 +1,589 @@
+// On-device recursions: the host logic of the reference's solvers with every
+// N-vector living in HBM.  Each iteration is one apply kernel (with a fused
+// epilogue where the recursion allows it) plus a few BLAS-1 kernels; only the
+// scalars the host-side tridiagonal / Chebyshev algebra needs cross PCIe.
+//
+// Reference functions followed (file:line under the reference repository):
+//   lanczos_extremal        src/Lanczos.jl:27-84
+//   estimate_energy_bounds  src/Lanczos.jl:255-271
+//   lanczos_groundstate     src/Lanczos.jl:87-181
+//   lanczos_tridiag         src/Lanczos.jl:196-246
+//   krylov_time_evolve      src/TimeEvolution/Krylov.jl:136-192
+//   chebyshev_time_evolve   src/TimeEvolution/Chebyshev.jl:61-124
+//   compute_chebyshev_moments / kpm_sw / kpm_sqw   src/KPM_Sqw.jl:34-128,191-256
+//   spectral_from_tridiagonal / lanczos_sqw        src/LanczosSqw.jl:18-80
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "sd_internal.hpp"
+
+namespace {
+
+struct DBuf {
+  double *p = nullptr;
+  DBuf() = default;
+  DBuf(const DBuf &) = delete;
+  DBuf &operator=(const DBuf &) = delete;
+  ~DBuf() { if (p) (void)hipFree(p); }
+  int alloc(sd_ctx *ctx, int64_t doubles) {
+    if (p) { (void)hipFree(p); p = nullptr; }
+    hipError_t e = hipMalloc((void **)&p, sizeof(double) * (size_t)std::max<int64_t>(doubles, 1));
+    if (e != hipSuccess) return sd_set_err(ctx, SD_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    return SD_OK;
+  }
+};
+
+#define RC(x) do { int rc__ = (x); if (rc__) return rc__; } while (0)
+
+int h2d(sd_ctx *ctx, double *d, const void *h, int64_t doubles) {
+  SD_HIP(ctx, hipMemcpyAsync(d, h, sizeof(double) * (size_t)doubles, hipMemcpyHostToDevice, ctx->stream));
+  SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SD_OK;
+}
+int d2h(sd_ctx *ctx, void *h, const double *d, int64_t doubles) {
+  SD_HIP(ctx, hipMemcpyAsync(h, d, sizeof(double) * (size_t)doubles, hipMemcpyDeviceToHost, ctx->stream));
+  SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SD_OK;
+}
+int d2d(sd_ctx *ctx, double *dst, const double *src, int64_t doubles) {
+  SD_HIP(ctx, hipMemcpyAsync(dst, src, sizeof(double) * (size_t)doubles, hipMemcpyDeviceToDevice, ctx->stream));
+  return SD_OK;
+}
+
+int check_unsharded(sd_ctx *ctx, const sd_model *m) {
+  if (!ctx) return SD_EARG;
+  if (!m || !m->dev_ready) return sd_set_err(ctx, SD_EARG, "model has no device tables");
+  if (m->nranks != 1) return sd_set_err(ctx, SD_EARG, "recursion-level entry points run on an unsharded model");
+  return SD_OK;
+}
+
+double norm_dev(sd_ctx *ctx, const double *x, int64_t n, int *rc) {
+  double v = 0.0;
+  *rc = sd_k_nrm2sq(ctx, x, n, 2);
+  if (!*rc) *rc = sd_read_scalars(ctx, 2, 1, &v);
+  return std::sqrt(v);
+}
+
+// lanczos_extremal on device vectors; d_start (2N doubles, un-normalised) is consumed
+int extremal_dev(sd_ctx *ctx, const sd_model *m, int lanc_m, double tol, double *v_prev, int negate,
+                 double *emin, double *emax) {
+  const int64_t N = m->N;
+  const int mm = (int)std::min<int64_t>(lanc_m, N);
+  if (mm < 1) return sd_set_err(ctx, SD_EARG, "lanc_m must be >= 1");
+  DBuf w, vc;
+  RC(w.alloc(ctx, 2 * N)); RC(vc.alloc(ctx, 2 * N));
+  double *v_curr = vc.p;
+  int rc = 0;
+  double nrm = norm_dev(ctx, v_prev, 2 * N, &rc); RC(rc);
+  RC(sd_k_scale_div(ctx, v_prev, v_prev, 2 * N, nrm));                     // :40
+  std::vector<double> alpha(mm, 0.0), beta(mm, 0.0);
+  int actual = mm;
+  sd_epi_args ea; ea.negate = negate;
+  for (int j = 1; j <= mm; ++j) {
+    RC(sd_launch_apply(ctx, m, SD_C128, w.p, v_prev, SD_EPI_DOT, ea));     // :51 + :55 fused
+    double s[2]; RC(sd_read_scalars(ctx, 0, 2, s));
+    alpha[j - 1] = s[0];
+    RC(sd_k_sub_axpby(ctx, w.p, v_prev, j == 1 ? nullptr : v_curr, 2 * N, alpha[j - 1], j == 1 ? 0.0 : beta[j - 2]));
+    if (j < mm) {
+      beta[j - 1] = norm_dev(ctx, w.p, 2 * N, &rc); RC(rc);               // :65
+      if (beta[j - 1] < tol) { actual = j; break; }                       // :66-70
+      std::swap(v_curr, v_prev);
+      RC(sd_k_scale_div(ctx, v_prev, w.p, 2 * N, beta[j - 1]));           // :71
+    }
+  }
+  std::vector<double> ev(actual);
+  int rce = sd_symtridiag_eig(actual, alpha.data(), beta.data(), ev.data(), nullptr);   // :80-83
+  if (rce) return sd_set_err(ctx, SD_EINTERNAL, "tridiagonal eigen-solver did not converge");
+  *emin = ev[0]; *emax = ev[actual - 1];
+  // note: v_prev / v_curr may have been swapped; the caller's buffer is scratch from here on
+  (void)hipStreamSynchronize(ctx->stream);
+  return SD_OK;
+}
+
+int start_vector(sd_ctx *ctx, double *d, const void *host, int64_t doubles, uint64_t seed) {
+  if (host) return h2d(ctx, d, host, doubles);
+  return sd_k_fill_randn(ctx, d, doubles, seed, 0);
+}
+
+int moments_dev(sd_ctx *ctx, const sd_model *m, const double *phi, int M, double a, double b, double *mu) {
+  // compute_chebyshev_moments  src/KPM_Sqw.jl:95-128  (phi: device, c128, normalised by the caller)
+  const int64_t N = m->N;
+  if (M < 2) return sd_set_err(ctx, SD_EARG, "kpm_m must be >= 2");
+  DBuf b0, b1, b2;
+  RC(b0.alloc(ctx, 2 * N)); RC(b1.alloc(ctx, 2 * N)); RC(b2.alloc(ctx, 2 * N));
+  double *v_prev = b0.p, *v_curr = b1.p, *v_next = b2.p;
+  RC(d2d(ctx, v_prev, phi, 2 * N));
+  double s[2];
+  RC(sd_k_dot(ctx, 2, phi, v_prev, N, 4)); RC(sd_read_scalars(ctx, 4, 2, s)); mu[0] = s[0];      // :103
+  sd_epi_args ea; ea.a = a; ea.b = b; ea.phi = phi;
+  RC(sd_launch_apply(ctx, m, SD_C128, v_curr, v_prev, SD_EPI_RESCALE_DOT, ea));                   // :106-107
+  RC(sd_read_scalars(ctx, 0, 2, s)); mu[1] = s[0];
+  for (int k = 2; k <= M - 1; ++k) {
+    ea.prev = v_prev;
+    RC(sd_launch_apply(ctx, m, SD_C128, v_next, v_curr, SD_EPI_KPM, ea));                         // :111-117 fused
+    RC(sd_read_scalars(ctx, 0, 2, s));
+    mu[k] = s[0];
+    const double nv = std::sqrt(s[1]);
+    if (nv > 1e3) RC(sd_k_scale_div(ctx, v_next, v_next, 2 * N, nv));                             // :118-121
+    double *t = v_prev; v_prev = v_curr; v_curr = v_next; v_next = t;                             // :124
+  }
+  return SD_OK;
+}
+
+int tridiag_dev(sd_ctx *ctx, const sd_model *m, double *vcur /* normalised start, consumed */, int lanc_m, double tol,
+                double *alpha, double *beta, int *m_eff_out) {
+  // lanczos_tridiag  src/Lanczos.jl:196-246 with two live vectors (the reference keeps all m)
+  const int64_t n = m->N;
+  const int mm = (int)std::min<int64_t>(lanc_m, n);
+  DBuf wb, vp;
+  RC(wb.alloc(ctx, 2 * n)); RC(vp.alloc(ctx, 2 * n));
+  double *w = wb.p, *vprev = vp.p;
+  for (int k = 0; k < mm; ++k) alpha[k] = 0.0;
+  for (int k = 0; k + 1 < mm; ++k) beta[k] = 0.0;
+  int m_eff = mm, rc = 0;
+  sd_epi_args ea;
+  for (int j = 1; j <= mm - 1; ++j) {
+    RC(sd_launch_apply(ctx, m, SD_C128, w, vcur, SD_EPI_DOT, ea));                                 // :218-219
+    double s[2]; RC(sd_read_scalars(ctx, 0, 2, s));
+    alpha[j - 1] = s[0];
+    RC(sd_k_sub2(ctx, w, vcur, j > 1 ? vprev : nullptr, 2 * n, alpha[j - 1], j > 1 ? beta[j - 2] : 0.0));  // :222-224
+    beta[j - 1] = norm_dev(ctx, w, 2 * n, &rc); RC(rc);                                           // :227
+    if (beta[j - 1] < tol) { m_eff = j; break; }
+    std::swap(vprev, vcur);
+    RC(sd_k_scale_div(ctx, vcur, w, 2 * n, beta[j - 1]));                                         // :233
+  }
+  if (m_eff == mm) {                                                                              // :237-239
+    RC(sd_launch_apply(ctx, m, SD_C128, w, vcur, SD_EPI_DOT, ea));
+    double s[2]; RC(sd_read_scalars(ctx, 0, 2, s));
+    alpha[mm - 1] = s[0];
+  }
+  *m_eff_out = m_eff;
+  return SD_OK;
+}
+
+}  // namespace
+
+// --------------------------------------------------------------------------
+// host numerics shared with the C ABI
+// --------------------------------------------------------------------------
+
+// Implicit-QL symmetric tridiagonal eigen-solver (stands in for LAPACK's
+// eigvals/eigen(SymTridiagonal) at src/Lanczos.jl:80-83,164-165,
+// src/TimeEvolution/Krylov.jl:175-176, src/LanczosSqw.jl:23-24).
+extern "C" int sd_symtridiag_eig(int n, const double *d_in, const double *e_in, double *w, double *z) {
+  if (n <= 0 || !d_in || !w) return SD_EARG;
+  std::vector<double> d(d_in, d_in + n), e(n, 0.0);
+  for (int i = 0; i + 1 < n; ++i) e[i] = e_in[i];
+  if (z) { std::fill(z, z + (size_t)n * n, 0.0); for (int i = 0; i < n; ++i) z[i + (size_t)n * i] = 1.0; }
+  const double eps = 2.220446049250313e-16;
+  for (int l = 0; l < n; ++l) {
+    int iter = 0, mm;
+    do {
+      for (mm = l; mm < n - 1; ++mm)
+        if (std::fabs(e[mm]) <= eps * (std::fabs(d[mm]) + std::fabs(d[mm + 1]))) break;
+      if (mm != l) {
+        if (iter++ == 300) return SD_EINTERNAL;
+        double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
+        double r = std::hypot(g, 1.0);
+        g = d[mm] - d[l] + e[l] / (g + std::copysign(r, g));
+        double s = 1.0, c = 1.0, pp = 0.0;
+        int i;
+        bool underflow = false;
+        for (i = mm - 1; i >= l; --i) {
+          double f = s * e[i], b = c * e[i];
+          r = std::hypot(f, g);
+          e[i + 1] = r;
+          if (r == 0.0) { d[i + 1] -= pp; e[mm] = 0.0; underflow = true; break; }
+          s = f / r; c = g / r;
+          g = d[i + 1] - pp;
+          r = (d[i] - g) * s + 2.0 * c * b;
+          pp = s * r;
+          d[i + 1] = g + pp;
+          g = c * r - b;
+          if (z)
+            for (int k = 0; k < n; ++k) {
+              double *zi = z + (size_t)n * i, *zi1 = z + (size_t)n * (i + 1);
+              const double f2 = zi1[k];
+              zi1[k] = s * zi[k] + c * f2;
+              zi[k] = c * zi[k] - s * f2;
+            }
+        }
+        if (underflow) continue;
+        d[l] -= pp; e[l] = g; e[mm] = 0.0;
+      }
+    } while (mm != l);
+  }
+  std::vector<int> order(n);
+  for (int i = 0; i < n; ++i) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return d[a] < d[b]; });
+  std::vector<double> zc;
+  if (z) zc.assign(z, z + (size_t)n * n);
+  for (int k = 0; k < n; ++k) {
+    w[k] = d[order[k]];
+    if (z) std::memcpy(z + (size_t)n * k, zc.data() + (size_t)n * order[k], sizeof(double) * n);
+  }
+  return SD_OK;
+}
+
+// c_k = (2 - delta_k0) * (-i)^k * J_k(a dt) * exp(-i b dt)   (src/TimeEvolution/Chebyshev.jl:74-79)
+extern "C" int sd_chebyshev_coeffs(int cheb_n, double a, double b, double dt, double *c) {
+  if (cheb_n < 1 || !c) return SD_EARG;
+  const double ph = b * dt, pr = std::cos(ph), pi = -std::sin(ph);
+  for (int k = 0; k < cheb_n; ++k) {
+    const double f = (k == 0) ? 1.0 : 2.0;
+    const double J = std::cyl_bessel_j((double)k, a * dt);   // besselj(k, x), integer order
+    double xr, xi;
+    switch (k & 3) {
+      case 0: xr = f; xi = 0; break;
+      case 1: xr = 0; xi = -f; break;
+      case 2: xr = -f; xi = 0; break;
+      default: xr = 0; xi = f; break;
+    }
+    xr *= J; xi *= J;
+    c[2 * k] = xr * pr - xi * pi;
+    c[2 * k + 1] = xr * pi + xi * pr;
+  }
+  return SD_OK;
+}
+
+extern "C" int sd_kpm_kernel(int M, int kernel, double *g) {
+  if (M < 1 || !g) return SD_EARG;
+  const double PI = 3.14159265358979323846;
+  for (int n = 0; n < M; ++n) g[n] = 1.0;
+  if (kernel == SD_KERNEL_JACKSON) {
+    for (int n = 0; n < M; ++n)
+      g[n] = ((M - n + 1) * std::cos(PI * n / (M + 1)) + std::sin(PI * n / (M + 1)) * (1.0 / std::tan(PI / (M + 1)))) / (M + 1);
+  } else if (kernel == SD_KERNEL_LORENTZ) {
+    const double lam = 3.0;
+    for (int n = 0; n < M; ++n) g[n] = std::sinh(lam * (1 - (double)n / M)) / std::sinh(lam);
+  }
+  return SD_OK;
+}
+
+extern "C" int sd_kpm_rescaling_from_bounds(double Emin, double Emax, double *a, double *b) {
+  if (!a || !b) return SD_EARG;
+  *a = (Emax - Emin) / (2 * 0.99);
+  *b = (Emax + Emin) / 2;
+  return SD_OK;
+}
+
+extern "C" int sd_kpm_reconstruct(const double *mu, int kpm_m, const double *omega, int W, double a, double b,
+                                  double E0, double *S) {
+  if (kpm_m < 1 || W < 0 || !mu || !S) return SD_EARG;
+  const double PI = 3.14159265358979323846;
+  std::vector<double> T(std::max(kpm_m, 2));
+  for (int iw = 0; iw < W; ++iw) {
+    const double x = (omega[iw] + E0 - b) / a;                       // src/KPM_Sqw.jl:61
+    if (std::fabs(x) >= 1.0) { S[iw] = 0.0; continue; }
+    T[0] = 1.0;
+    if (kpm_m >= 2) T[1] = x;
+    for (int n = 2; n < kpm_m; ++n) T[n] = 2.0 * x * T[n - 1] - T[n - 2];
+    double sum_val = mu[0] * T[0];
+    for (int n = 1; n < kpm_m; ++n) sum_val += 2.0 * mu[n] * T[n];
+    const double denom = PI * std::sqrt(1.0 - x * x);
+    const double v = sum_val / (a * denom);
+    S[iw] = v > 0.0 ? v : 0.0;
+  }
+  return SD_OK;
+}
+
+extern "C" int sd_spectral_from_tridiagonal(const double *alpha, const double *beta, int mt, double norm_phi, double E0,
+                                            const double *omega, int W, double eta, int broaden, double *S) {
+  if (mt < 1 || !alpha || !S) return SD_EARG;
+  if (broaden != SD_BROADEN_LORENTZ && broaden != SD_BROADEN_GAUSS) return SD_EARG;
+  const double PI = 3.14159265358979323846;
+  std::vector<double> th(mt), Q((size_t)mt * mt);
+  int rc = sd_symtridiag_eig(mt, alpha, beta, th.data(), Q.data());
+  if (rc) return rc;
+  for (int iw = 0; iw < W; ++iw) {
+    double s = 0.0;
+    for (int k = 0; k < mt; ++k) {
+      const double q1 = Q[(size_t)mt * k];
+      const double wgt = q1 * q1 * (norm_phi * norm_phi);
+      const double sh = omega[iw] - (th[k] - E0);
+      const double f = broaden == SD_BROADEN_LORENTZ ? (1 / PI) * (eta / (sh * sh + eta * eta))
+                                                     : (1 / (std::sqrt(2 * PI) * eta)) * std::exp(-(sh * sh) / (2 * eta * eta));
+      s += f * wgt;
+    }
+    S[iw] = s;
+  }
+  return SD_OK;
+}
+
+// --------------------------------------------------------------------------
+// recursion-level C ABI
+// --------------------------------------------------------------------------
+
+extern "C" int sd_lanczos_extremal(sd_ctx *ctx, const sd_model *m, int lanc_m, double tol, const void *psi0,
+                                   uint64_t seed, int negate, double *emin, double *emax) {
+  RC(check_unsharded(ctx, m));
+  if (!emin || !emax) return sd_set_err(ctx, SD_EARG, "null output");
+  DBuf v; RC(v.alloc(ctx, 2 * m->N));
+  RC(start_vector(ctx, v.p, psi0, 2 * m->N, seed));
+  return extremal_dev(ctx, m, lanc_m, tol, v.p, negate, emin, emax);
+}
+
+extern "C" int sd_energy_bounds(sd_ctx *ctx, const sd_model *m, int lanc_m, const void *psi0_a, const void *psi0_b,
+                                uint64_t seed, double *Emin, double *Emax) {
+  RC(check_unsharded(ctx, m));
+  if (!Emin || !Emax) return sd_set_err(ctx, SD_EARG, "null output");
+  double lo, hi;
+  {
+    DBuf v; RC(v.alloc(ctx, 2 * m->N));
+    RC(start_vector(ctx, v.p, psi0_a, 2 * m->N, seed));
+    RC(extremal_dev(ctx, m, lanc_m, 1e-12, v.p, 0, &lo, &hi));          // src/Lanczos.jl:258
+    *Emax = hi;
+  }
+  {
+    DBuf v; RC(v.alloc(ctx, 2 * m->N));
+    RC(start_vector(ctx, v.p, psi0_b, 2 * m->N, seed + 0x9E3779B97F4A7C15ULL));
+    RC(extremal_dev(ctx, m, lanc_m, 1e-12, v.p, 1, &lo, &hi));          // :261-267
+    *Emin = -hi;
+  }
+  return SD_OK;
+}
+
+extern "C" int sd_lanczos_groundstate(sd_ctx *ctx, const sd_model *m, int lanc_m, double tol, double orth_tol,
+                                      const double *psi0, uint64_t seed, double *E0, double *psi_gs, int *m_actual_out) {
+  RC(check_unsharded(ctx, m));
+  if (!E0 || !psi_gs) return sd_set_err(ctx, SD_EARG, "null output");
+  const int64_t N = m->N;
+  const int mm = (int)std::min<int64_t>(lanc_m, N);
+  if (mm < 1) return sd_set_err(ctx, SD_EARG, "lanc_m must be >= 1");
+  DBuf V, w, tmp;
+  RC(V.alloc(ctx, N * (int64_t)mm)); RC(w.alloc(ctx, N)); RC(tmp.alloc(ctx, N));
+  RC(start_vector(ctx, V.p, psi0, N, seed));
+  int rc = 0;
+  double nrm = norm_dev(ctx, V.p, N, &rc); RC(rc);
+  RC(sd_k_scale_div(ctx, V.p, V.p, N, nrm));                                             // :100,105
+  std::vector<double> alpha(mm, 0.0), beta(mm, 0.0);
+  int m_actual = mm;
+  sd_epi_args ea;
+  for (int j = 1; j <= mm; ++j) {
+    double *vj = V.p + N * (int64_t)(j - 1);
+    RC(sd_launch_apply(ctx, m, SD_F64, w.p, vj, SD_EPI_PLAIN, ea));                       // :113
+    double s[2];
+    for (int k = 1; k <= j - 1; ++k) {                                                   // :116-122
+      double *vk = V.p + N * (int64_t)(k - 1);
+      RC(sd_k_dot(ctx, 1, vk, w.p, N, 4)); RC(sd_read_scalars(ctx, 4, 1, s));
+      RC(sd_k_sub2(ctx, w.p, vk, nullptr, N, s[0], 0.0));
+    }
+    RC(sd_k_dot(ctx, 1, vj, w.p, N, 4)); RC(sd_read_scalars(ctx, 4, 1, s));
+    alpha[j - 1] = s[0];                                                                 // :124
+    RC(sd_k_sub2(ctx, w.p, vj, j == 1 ? nullptr : V.p + N * (int64_t)(j - 2), N, alpha[j - 1],
+                 j == 1 ? 0.0 : beta[j - 2]));                                           // :127-129
+    if (j < mm) {
+      beta[j - 1] = norm_dev(ctx, w.p, N, &rc); RC(rc);                                  // :133
+      if (beta[j - 1] < tol) { m_actual = j; break; }                                    // :136-139
+      bool tmp_valid = false;
+      for (int k = 1; k <= j; ++k) {                                                     // :142-153
+        double *vk = V.p + N * (int64_t)(k - 1);
+        if (!tmp_valid) { RC(sd_k_scale_div(ctx, tmp.p, w.p, N, beta[j - 1])); tmp_valid = true; }
+        RC(sd_k_dot(ctx, 1, vk, tmp.p, N, 4)); RC(sd_read_scalars(ctx, 4, 1, s));
+        if (std::fabs(s[0]) > orth_tol) {
+          RC(sd_k_dot(ctx, 1, vk, w.p, N, 4)); RC(sd_read_scalars(ctx, 4, 1, s));
+          RC(sd_k_sub2(ctx, w.p, vk, nullptr, N, s[0], 0.0));
+          beta[j - 1] = norm_dev(ctx, w.p, N, &rc); RC(rc);
+          tmp_valid = false;
+          if (beta[j - 1] < tol) { m_actual = j; break; }                               // inner break only (:150)
+        }
+      }
+      RC(sd_k_scale_div(ctx, V.p + N * (int64_t)j, w.p, N, beta[j - 1]));                 // :155
+    }
+  }
+  std::vector<double> ev(m_actual), Z((size_t)m_actual * m_actual);
+  if (sd_symtridiag_eig(m_actual, alpha.data(), beta.data(), ev.data(), Z.data()))       // :164-165
+    return sd_set_err(ctx, SD_EINTERNAL, "tridiagonal eigen-solver did not converge");
+  *E0 = ev[0];                                                                           // :167
+  RC(sd_k_gemv_cols(ctx, w.p, V.p, N, m_actual, Z.data()));                              // :170 (first eigenvector = column 0)
+  nrm = norm_dev(ctx, w.p, N, &rc); RC(rc);
+  RC(sd_k_scale_div(ctx, w.p, w.p, N, nrm));                                             // :171
+  RC(d2h(ctx, psi_gs, w.p, N));
+  if (m_actual_out) *m_actual_out = m_actual;
+  return SD_OK;
+}
+
+extern "C" int sd_lanczos_tridiag(sd_ctx *ctx, const sd_model *m, const void *v, int64_t n, int lanc_m, double tol,
+                                  double *alpha, double *beta, int *m_eff, double *norm_v) {
+  RC(check_unsharded(ctx, m));
+  if (n != m->N) return sd_set_err(ctx, SD_EDIM, "vector length does not match the basis dimension");
+  if (!v || !alpha || !beta || !m_eff || !norm_v) return sd_set_err(ctx, SD_EARG, "null argument");
+  if (lanc_m < 1) return sd_set_err(ctx, SD_EARG, "lanc_m must be >= 1");
+  DBuf vc; RC(vc.alloc(ctx, 2 * n));
+  RC(h2d(ctx, vc.p, v, 2 * n));
+  int rc = 0;
+  const double normv = norm_dev(ctx, vc.p, 2 * n, &rc); RC(rc);
+  if (normv == 0) return sd_set_err(ctx, SD_EZERO, "starting vector has zero norm");     // :210-212
+  RC(sd_k_scale_div(ctx, vc.p, vc.p, 2 * n, normv));
+  *norm_v = normv;
+  return tridiag_dev(ctx, m, vc.p, lanc_m, tol, alpha, beta, m_eff);
+}
+
+extern "C" int sd_krylov_evolve(sd_ctx *ctx, const sd_model *m, int dtype, const void *psi0, int64_t n, double dt,
+                                int kry_m, void *psit) {
+  RC(check_unsharded(ctx, m));
+  if (n != m->N) return sd_set_err(ctx, SD_EDIM, "vector length does not match the basis dimension");
+  if (dtype != SD_F64 && dtype != SD_C128) return sd_set_err(ctx, SD_EARG, "bad dtype");
+  if (kry_m < 1) return sd_set_err(ctx, SD_EARG, "kry_m must be >= 1");
+  const int nc = dtype == SD_C128 ? 2 : 1;
+  // all Krylov vectors are kept complex on the device; a real psi0 keeps exactly-zero imaginary parts
+  std::vector<DBuf> V(kry_m);
+  DBuf in, w;
+  RC(in.alloc(ctx, nc * n)); RC(w.alloc(ctx, 2 * n));
+  RC(h2d(ctx, in.p, psi0, nc * n));
+  int rc = 0;
+  const double norm0 = norm_dev(ctx, in.p, nc * n, &rc); RC(rc);
+  RC(V[0].alloc(ctx, 2 * n));
+  RC(sd_k_promote(ctx, V[0].p, in.p, nc, n));
+  if (norm0 == 0) { RC(d2h(ctx, psit, V[0].p, 2 * n)); return SD_OK; }                    // :145-147
+  RC(sd_k_scale_div(ctx, V[0].p, V[0].p, 2 * n, norm0));                                  // :148
+  std::vector<double> alr(kry_m, 0.0), beta(kry_m, 0.0);
+  int m_eff = kry_m;
+  sd_epi_args ea;
+  for (int j = 1; j <= kry_m; ++j) {
+    RC(sd_launch_apply(ctx, m, SD_C128, w.p, V[j - 1].p, SD_EPI_DOT, ea));                // :153,155
+    double s[2]; RC(sd_read_scalars(ctx, 0, 2, s));
+    alr[j - 1] = s[0];
+    RC(sd_k_csub(ctx, w.p, V[j - 1].p, n, s[0], s[1]));                                   // :156
+    if (j > 1) RC(sd_k_sub2(ctx, w.p, V[j - 2].p, nullptr, 2 * n, beta[j - 2], 0.0));      // :157-159
+    if (j < kry_m) {
+      beta[j - 1] = norm_dev(ctx, w.p, 2 * n, &rc); RC(rc);                               // :161
+      if (std::fabs(beta[j - 1]) < 1e-14) { m_eff = j; break; }                           // :162-168
+      RC(V[j].alloc(ctx, 2 * n));
+      RC(sd_k_scale_div(ctx, V[j].p, w.p, 2 * n, beta[j - 1]));                           // :169
+    }
+  }
+  // reduced problem on the host (:175-182).  Deviation (documented in DESIGN.md): Re(alpha) enters a
+  // symmetric tridiagonal solve instead of the reference's general complex eigen of the same matrix.
+  std::vector<double> ev(m_eff), Q((size_t)m_eff * m_eff), yr(m_eff, 0.0), yi(m_eff, 0.0);
+  if (sd_symtridiag_eig(m_eff, alr.data(), beta.data(), ev.data(), Q.data()))
+    return sd_set_err(ctx, SD_EINTERNAL, "tridiagonal eigen-solver did not converge");
+  for (int l = 0; l < m_eff; ++l) {
+    const double ph = -ev[l] * dt, cr = std::cos(ph), ci = std::sin(ph);
+    const double q0 = Q[(size_t)m_eff * l] * norm0;
+    for (int k = 0; k < m_eff; ++k) {
+      const double qk = Q[k + (size_t)m_eff * l];
+      yr[k] += qk * cr * q0; yi[k] += qk * ci * q0;
+    }
+  }
+  SD_HIP(ctx, hipMemsetAsync(w.p, 0, sizeof(double) * 2 * n, ctx->stream));             // :185
+  for (int k = 0; k < m_eff; ++k) RC(sd_k_cacc(ctx, w.p, V[k].p, n, yr[k], yi[k]));       // :186-188
+  const double nn = norm_dev(ctx, w.p, 2 * n, &rc); RC(rc);
+  RC(sd_k_scale_div(ctx, w.p, w.p, 2 * n, nn));                                           // :190
+  RC(d2h(ctx, psit, w.p, 2 * n));
+  return SD_OK;
+}
+
+extern "C" int sd_chebyshev_evolve(sd_ctx *ctx, const sd_model *m, const void *psi0, int64_t n, double dt, int cheb_n,
+                                   double Emin, double Emax, void *psit) {
+  RC(check_unsharded(ctx, m));
+  if (n != m->N) return sd_set_err(ctx, SD_EDIM, "vector length does not match the basis dimension");
+  if (cheb_n < 1) return sd_set_err(ctx, SD_EARG, "cheb_n must be >= 1");               // :65
+  const double a = (Emax - Emin) / (2 * 0.9999), b = (Emax + Emin) / 2;                   // :70-71
+  std::vector<double> c(2 * (size_t)cheb_n);
+  sd_chebyshev_coeffs(cheb_n, a, b, dt, c.data());
+  DBuf b0, b1, b2, pt;
+  RC(b0.alloc(ctx, 2 * n)); RC(b1.alloc(ctx, 2 * n)); RC(b2.alloc(ctx, 2 * n)); RC(pt.alloc(ctx, 2 * n));
+  double *pprev = b0.p, *pcur = b1.p, *pnext = b2.p;
+  RC(h2d(ctx, pprev, psi0, 2 * n));                                                       // :90
+  sd_epi_args ea; ea.a = a; ea.b = b;
+  RC(sd_launch_apply(ctx, m, SD_C128, pcur, pprev, SD_EPI_RESCALE, ea));                  // :93
+  RC(sd_k_cheb_init(ctx, pt.p, pprev, pcur, n, c[0], c[1], cheb_n >= 2 ? c[2] : 0.0, cheb_n >= 2 ? c[3] : 0.0,
+                    cheb_n >= 2));                                                        // :96-102
+  for (int k = 2; k <= cheb_n - 1; ++k) {                                                 // :110-121, one fused pass per term
+    ea.prev = pprev; ea.accv = pt.p; ea.c_re = c[2 * k]; ea.c_im = c[2 * k + 1];
+    RC(sd_launch_apply(ctx, m, SD_C128, pnext, pcur, SD_EPI_CHEB, ea));
+    double *t = pprev; pprev = pcur; pcur = pnext; pnext = t;
+  }
+  RC(d2h(ctx, psit, pt.p, 2 * n));
+  return SD_OK;
+}
+
+extern "C" int sd_kpm_moments(sd_ctx *ctx, const sd_model *m, const void *phi, int64_t n, int M, double a, double b,
+                              double *mu) {
+  RC(check_unsharded(ctx, m));
+  if (n != m->N) return sd_set_err(ctx, SD_EDIM, "vector length does not match the basis dimension");
+  if (!phi || !mu) return sd_set_err(ctx, SD_EARG, "null argument");
+  DBuf ph; RC(ph.alloc(ctx, 2 * n));
+  RC(h2d(ctx, ph.p, phi, 2 * n));
+  return moments_dev(ctx, m, ph.p, M, a, b, mu);
+}
+
+extern "C" int sd_kpm_sqw(sd_ctx *ctx, const sd_model *m, int dtype, const void *psi0, int64_t n, const double *q, int Qn,
+                          const double *omega, int W, int have_ab, double a, double b, int kpm_m, int kernel,
+                          uint64_t seed, double *Smat) {
+  RC(check_unsharded(ctx, m));
+  if (n != m->N) return sd_set_err(ctx, SD_EDIM, "vector length does not match the basis dimension");
+  if (dtype != SD_F64 && dtype != SD_C128) return sd_set_err(ctx, SD_EARG, "bad dtype");
+  if (kpm_m < 2) return sd_set_err(ctx, SD_EARG, "kpm_m must be >= 2");
+  const int nc = dtype == SD_C128 ? 2 : 1;
+  DBuf in, psic, tmp, phi;
+  RC(in.alloc(ctx, nc * n)); RC(psic.alloc(ctx, 2 * n)); RC(tmp.alloc(ctx, 2 * n)); RC(phi.alloc(ctx, 2 * n));
+  RC(h2d(ctx, in.p, psi0, nc * n));
+  RC(sd_k_promote(ctx, psic.p, in.p, nc, n));                                             // :202
+  sd_epi_args ea;
+  RC(sd_launch_apply(ctx, m, SD_C128, tmp.p, psic.p, SD_EPI_DOT, ea));                    // :208-209
+  double s[2]; RC(sd_read_scalars(ctx, 0, 2, s));
+  const double E0 = s[0];
+  if (!have_ab) {                                                                         // :212-214
+    double Emin, Emax;
+    RC(sd_energy_bounds(ctx, m, 80, nullptr, nullptr, seed, &Emin, &Emax));
+    sd_kpm_rescaling_from_bounds(Emin, Emax, &a, &b);
+  }
+  std::vector<double> mu(kpm_m), g(kpm_m);
+  sd_kpm_kernel(kpm_m, kernel, g.data());
+  int rc = 0;
+  for (int iq = 0; iq < Qn; ++iq) {                                                       // :218 (serial over q)
+    double *Srow = Smat + (size_t)iq * W;
+    RC(sd_launch_szq(ctx, m, SD_C128, psic.p, q[iq], phi.p));                             // :223
+    const double norm_phi = norm_dev(ctx, phi.p, 2 * n, &rc); RC(rc);
+    if (norm_phi == 0) { for (int iw = 0; iw < W; ++iw) Srow[iw] = 0.0; continue; }       // :226-229
+    RC(sd_k_scale_div(ctx, phi.p, phi.p, 2 * n, norm_phi));                               // :231
+    RC(moments_dev(ctx, m, phi.p, kpm_m, a, b, mu.data()));
+    for (int k = 0; k < kpm_m; ++k) mu[k] *= g[k];                                        // :53
+    sd_kpm_reconstruct(mu.data(), kpm_m, omega, W, a, b, E0, Srow);
+    const double n2 = norm_phi * norm_phi;
+    for (int iw = 0; iw < W; ++iw) Srow[iw] *= n2;                                        // :252
+  }
+  return SD_OK;
+}
+
+extern "C" int sd_lanczos_sqw(sd_ctx *ctx, const sd_model *m, int dtype, const void *psi0, int64_t n, const double *q,
+                              int Qn, const double *omega, int W, int lanc_m, double eta, int broaden, double *Smat) {
+  RC(check_unsharded(ctx, m));
+  if (n != m->N) return sd_set_err(ctx, SD_EDIM, "vector length does not match the basis dimension");
+  if (dtype != SD_F64 && dtype != SD_C128) return sd_set_err(ctx, SD_EARG, "bad dtype");
+  if (broaden != SD_BROADEN_LORENTZ && broaden != SD_BROADEN_GAUSS) return sd_set_err(ctx, SD_EARG, "unknown broadening");
+  if (lanc_m < 1) return sd_set_err(ctx, SD_EARG, "lanc_m must be >= 1");
+  const int nc = dtype == SD_C128 ? 2 : 1;
+  DBuf in, psic, tmp, phi;
+  RC(in.alloc(ctx, nc * n)); RC(psic.alloc(ctx, 2 * n)); RC(tmp.alloc(ctx, 2 * n)); RC(phi.alloc(ctx, 2 * n));
+  RC(h2d(ctx, in.p, psi0, nc * n));
+  RC(sd_k_promote(ctx, psic.p, in.p, nc, n));
+  sd_epi_args ea;
+  RC(sd_launch_apply(ctx, m, SD_C128, tmp.p, psic.p, SD_EPI_PLAIN, ea));                  // src/LanczosSqw.jl:58
+  // E0 = real(dot(conj(psi0c), tmp)) = Re sum psi_i*tmp_i (sic, :59): conj(conj(psi)).tmp -> use dot with conj(psi)
+  // Re sum (pr + i pi)(tr + i ti) = sum pr*tr - pi*ti.  Computed as dot(psi, tmp') with tmp' = conj(tmp):
+  // Re<psi|conj(tmp)> = sum pr*tr - pi*ti.  We get it from two real dots of the interleaved arrays.
+  std::vector<double> hp(2 * (size_t)n), ht(2 * (size_t)n);
+  RC(d2h(ctx, hp.data(), psic.p, 2 * n)); RC(d2h(ctx, ht.data(), tmp.p, 2 * n));
+  double E0 = 0.0;
+  for (int64_t i = 0; i < n; ++i) E0 += hp[2 * i] * ht[2 * i] - hp[2 * i + 1] * ht[2 * i + 1];
+  const int mm = (int)std::min<int64_t>(lanc_m, n);
+  std::vector<double> alpha(mm), beta(std::max(mm, 1));
+  int rc = 0;
+  for (int iq = 0; iq < Qn; ++iq) {
+    double *Srow = Smat + (size_t)iq * W;
+    RC(sd_launch_szq(ctx, m, SD_C128, psic.p, q[iq], phi.p));
+    const double normv = norm_dev(ctx, phi.p, 2 * n, &rc); RC(rc);
+    if (normv == 0) { for (int iw = 0; iw < W; ++iw) Srow[iw] = 0.0; continue; }          // :67-70
+    RC(sd_k_scale_div(ctx, phi.p, phi.p, 2 * n, normv));
+    int m_eff = 0;
+    RC(tridiag_dev(ctx, m, phi.p, lanc_m, 1e-12, alpha.data(), beta.data(), &m_eff));     // :73
+    int rs = sd_spectral_from_tridiagonal(alpha.data(), beta.data(), m_eff, normv, E0, omega, W, eta, broaden, Srow);
+    if (rs) return sd_set_err(ctx, rs, "spectral_from_tridiagonal failed");
+  }
+  return SD_OK;
+}

@@ -1,0 +1,164 @@
+// Internal declarations of libspindyn (not part of the C ABI).
+//
+// Basis layout (what every kernel relies on).  The reference enumerates a
+// fixed-nup sector with Combinatorics.combinations(1:L, nup) (src/Basis.jl:41),
+// i.e. lexicographically over sorted site lists, site i <-> bit i-1.  That
+// order is a binary tree over the sites 1,2,...,L with the "site up" child
+// first, so
+//     idx0(s) = sum over sites k with bit_k = 0 and r_k >= 1 of C(L-k, r_k-1),
+//     r_k = nup - (#up among sites < k).
+// We split the sites into a PREFIX (sites 1..p, low bits) and a SUFFIX (sites
+// p+1..L, LS = L-p high bits).  All rows sharing a prefix configuration P
+// (j = popcount(P) ups) are contiguous -- a TILE -- and inside a tile they are
+// ordered exactly like the sector (LS, nup-j).  Hence
+//     state(row) = P | suf_states[nup-j][row - base(P)] << p
+//     idx0(s)    = base(P) + suf_rank[s >> p].
+// A hop on a bond inside the prefix maps a whole tile onto another whole tile
+// (same internal order); the bond straddling prefix/suffix maps a contiguous
+// half of a tile onto a contiguous half of another tile; bonds inside the
+// suffix stay inside the tile (served from LDS).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/spindyn.h"
+
+#define SD_MAX_L 63
+#define SD_MAX_BONDS 4096  // bond lists are uploaded to device memory; this bounds host validation only
+#define SD_MAX_PREFIX_BITS 26
+
+struct sd_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  std::string err;
+  // scratch for block partial sums / reduced scalars
+  double *d_partials = nullptr;
+  size_t partials_cap = 0;  // doubles
+  double *d_scalars = nullptr;  // 16 doubles, device
+  double *h_scalars = nullptr;  // 16 doubles, pinned host
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+// Device-side view of a model, passed by value to kernels.
+struct sd_dev_model {
+  int L, nup;            // nup < 0: full basis
+  int p, LS;             // prefix / suffix site counts (tiled path); p = -1 when untiled
+  int n_hop, n_zz;
+  int nn_hops;           // leading hops that are exactly (1,2),(2,3),...,(L-1,L) in order (L-1 or 0)
+  int diag_mode;         // 0 exact list order, 1 uniform closed form
+  double diag_q;         // Jz/4 for diag_mode 1
+  int n_zz_nn;           // leading zz bonds that are the NN chain in order (L-1 or 0), for diag_mode 1
+  int field_zero;
+  int64_t N;             // global dimension
+  int64_t n_local;       // rows owned by this shard (== N unsharded)
+  int64_t row_lo;        // first owned global row
+  const int *hop_i, *hop_j;      // 1-based sites
+  const double *hop_J;
+  const int *zz_i, *zz_j;
+  const double *zz_J;
+  const double *field;
+  const int64_t *binom;  // (SD_MAX_L+1) x (SD_MAX_L+1) row-major: C(n,k)
+  // tiled path tables
+  int n_tiles;
+  const uint32_t *tile_prefix;   // per local tile (processing order)
+  const int64_t *tile_base;      // per local tile: offset of its first row in the local vector
+  const int64_t *addr;           // 2^p entries: offset of tile P in [local | halo], -1 if unavailable
+  const uint16_t *suf_states;    // concatenated sectors (LS, t'), t' = 0..LS
+  const int32_t *suf_off;        // LS+2 offsets into suf_states
+  const uint16_t *suf_rank;      // 2^LS entries: rank of sigma inside its sector
+};
+
+struct sd_model {
+  sd_ctx *ctx = nullptr;  // may be null (host-only model)
+  int L = 0, nup = -1;
+  int64_t N = 0;
+  std::vector<int> hop_i, hop_j, zz_i, zz_j;
+  std::vector<double> hop_J, zz_J, field;
+  std::vector<int64_t> binom;  // host copy
+  // plan
+  int p = -1, LS = 0;
+  int rank = 0, nranks = 1;
+  int64_t row_lo = 0, row_hi = 0, n_local = 0, n_halo = 0;
+  std::vector<uint32_t> tile_prefix;  // local tiles
+  std::vector<int64_t> tile_base;
+  std::vector<int64_t> addr;
+  std::vector<uint16_t> suf_states, suf_rank;
+  std::vector<int32_t> suf_off;
+  std::vector<sd_slab> recv_slabs, send_slabs;
+  int max_tile_len = 0;
+  // device copies
+  sd_dev_model dm{};
+  std::vector<void *> dev_allocs;
+  bool dev_ready = false;
+};
+
+// ---- host basis helpers (basis.cpp) ----
+int64_t sd_binom(int n, int k);
+void sd_fill_binom(std::vector<int64_t> &tab);
+uint64_t sd_unrank_host(const sd_model *m, int64_t idx0);
+int64_t sd_rank_host(const sd_model *m, uint64_t s);  // -1 if not in the basis
+int sd_build_plan(sd_model *m, int rank, int nranks, std::string &err);
+int sd_upload_model(sd_model *m, std::string &err);
+void sd_free_device_tables(sd_model *m);
+
+// ---- kernels (launch wrappers; *.hip) ----
+enum sd_epilogue {
+  SD_EPI_PLAIN = 0,     // out = H psi
+  SD_EPI_RESCALE = 1,   // out = (H psi - b psi)/a
+  SD_EPI_CHEB = 2,      // out = 2*(H psi - b psi)/a - prev ; acc_vec += c*out
+  SD_EPI_KPM = 3,       // out = 2*(H psi - b psi)/a - prev ; partial sums Re<phi|out>, |out|^2
+  SD_EPI_DOT = 4,       // out = H psi ; partial sums <psi|out> (re, im)
+  SD_EPI_RESCALE_DOT = 5  // out = (H psi - b psi)/a ; partial sums Re<phi|out>, |out|^2
+};
+struct sd_epi_args {
+  double a = 1.0, b = 0.0;
+  double c_re = 0.0, c_im = 0.0;
+  const void *prev = nullptr;   // phi_prev / v_prev
+  void *accv = nullptr;         // psi_t (CHEB)
+  const void *phi = nullptr;    // KPM reference vector
+  int negate = 0;               // PLAIN / DOT: out = -(H psi)
+};
+// Launches the apply with the chosen epilogue.  When the epilogue produces
+// partial sums, the reduced values land in ctx->d_scalars[0..1] (device).
+int sd_launch_apply(sd_ctx *ctx, const sd_model *m, int dtype, void *out, const void *psi, int epi,
+                    const sd_epi_args &ea);
+int sd_launch_szq(sd_ctx *ctx, const sd_model *m, int dtype_in, const void *psi0, double q, void *phi);
+
+// BLAS-1 style kernels on device vectors of `n` doubles (n = nc * N).
+// Reductions write their result to ctx->d_scalars[slot..] (device memory) in a
+// fixed, deterministic order; sd_read_scalars copies them to the host.
+int sd_k_dot(sd_ctx *ctx, int nc, const double *x, const double *y, int64_t N, int slot);  // conj(x).y -> [slot]=re,[slot+1]=im
+int sd_k_nrm2sq(sd_ctx *ctx, const double *x, int64_t n, int slot);
+int sd_read_scalars(sd_ctx *ctx, int slot, int count, double *out);
+int sd_k_scale_div(sd_ctx *ctx, double *y, const double *x, int64_t n, double d);      // y = x / d
+int sd_k_neg(sd_ctx *ctx, double *x, int64_t n);
+// w = w - (a*v + b*u)   (lanczos_extremal form, src/Lanczos.jl:59-61); u may be null (b ignored)
+int sd_k_sub_axpby(sd_ctx *ctx, double *w, const double *v, const double *u, int64_t n, double a, double b);
+// w = (w - a*v) - b*u   (two roundings: src/Lanczos.jl:222-224, :127-129); u may be null
+int sd_k_sub2(sd_ctx *ctx, double *w, const double *v, const double *u, int64_t n, double a, double b);
+// w -= (ar + i ai) * v  for complex vectors (src/TimeEvolution/Krylov.jl:156)
+int sd_k_csub(sd_ctx *ctx, double *w, const double *v, int64_t N, double ar, double ai);
+// y += (ar + i ai) * x  complex accumulate (Krylov reconstruction :186-188)
+int sd_k_cacc(sd_ctx *ctx, double *y, const double *x, int64_t N, double ar, double ai);
+// y = c0*x0 (+ c1*x1) complex  (Chebyshev start, src/TimeEvolution/Chebyshev.jl:96-102)
+int sd_k_cheb_init(sd_ctx *ctx, double *y, const double *x0, const double *x1, int64_t N, double c0r, double c0i,
+                   double c1r, double c1i, int have1);
+// complex <- real promotion / copy
+int sd_k_promote(sd_ctx *ctx, double *yc, const double *x, int nc_in, int64_t N);
+// y[i] = sum_k V[i + N*k] * coef[k]  (real, ground-state reconstruction src/Lanczos.jl:170); coef on host
+int sd_k_gemv_cols(sd_ctx *ctx, double *y, const double *V, int64_t N, int ncols, const double *coef_host);
+int sd_k_fill_randn(sd_ctx *ctx, double *x, int64_t n, uint64_t seed, uint64_t first);
+double sd_randn_host(uint64_t seed, uint64_t k);
+
+// error helpers
+int sd_set_err(sd_ctx *ctx, int code, const std::string &msg);
+#define SD_HIP(ctx, call)                                                                       \
+  do {                                                                                          \
+    hipError_t e__ = (call);                                                                    \
+    if (e__ != hipSuccess)                                                                      \
+      return sd_set_err((ctx), SD_EHIP, std::string(#call) + ": " + hipGetErrorString(e__));   \
+  } while (0)

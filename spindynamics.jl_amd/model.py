@@ -1,0 +1,134 @@
+"""Mirror of the reference's SpinModel module (src/SpinModel.jl) on top of sd_model.
+
+`Model` carries the same descriptor fields as SpinModel.Model (:6-15) except
+`states` / `idxmap`, which are never materialised for the full dimension: the
+library reproduces the basis order of build_sector_basis (src/Basis.jl:37-53)
+from closed-form ranking.  `model.states` is computed on demand for parity
+checks.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import ArgumentError, check, lib
+
+
+def _arr(vals, dtype):
+    return np.ascontiguousarray(np.array(list(vals), dtype=dtype))
+
+
+class Model:
+    def __init__(self, L, nup=None, hopping=(), onsite_field=None, zz=(), ctx="default"):
+        if not isinstance(L, (int, np.integer)):
+            raise ArgumentError("L must be an integer")
+        self.L = int(L)
+        self.nup = None if nup is None else int(nup)
+        self.mode = "full" if nup is None else "sector"
+        self.hopping_list = [(int(i), int(j), float(J)) for (i, j, J) in hopping]
+        self.zz_list = [(int(i), int(j), float(J)) for (i, j, J) in zz]
+        if onsite_field is None:
+            onsite_field = np.zeros(max(self.L, 0))
+        self.onsite_field = np.ascontiguousarray(onsite_field, dtype=np.float64)
+        if self.L >= 1 and len(self.onsite_field) != self.L:
+            raise ArgumentError("onsite_field must have L entries")
+        self.ctx = _lib.default_context() if ctx == "default" else ctx
+        hi = _arr((h[0] for h in self.hopping_list), np.int32)
+        hj = _arr((h[1] for h in self.hopping_list), np.int32)
+        hJ = _arr((h[2] for h in self.hopping_list), np.float64)
+        zi = _arr((h[0] for h in self.zz_list), np.int32)
+        zj = _arr((h[1] for h in self.zz_list), np.int32)
+        zJ = _arr((h[2] for h in self.zz_list), np.float64)
+        ip, dp = C.POINTER(C.c_int), C.POINTER(C.c_double)
+        self.h = C.c_void_p()
+        ch = self.ctx.h if self.ctx is not None else None
+        check(lib().sd_model_create(ch, self.L, -1 if self.nup is None else self.nup,
+                                    len(hi), hi.ctypes.data_as(ip), hj.ctypes.data_as(ip), hJ.ctypes.data_as(dp),
+                                    len(zi), zi.ctypes.data_as(ip), zj.ctypes.data_as(ip), zJ.ctypes.data_as(dp),
+                                    self.onsite_field.ctypes.data_as(dp), C.byref(self.h)), ch)
+        self.N = int(lib().sd_model_dim(self.h))
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                lib().sd_model_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def __len__(self):
+        return self.N
+
+    # -- basis queries (host) --
+    def states_range(self, start, count):
+        out = np.empty(count, dtype=np.uint64)
+        check(lib().sd_model_states(self.h, start, count, out.ctypes.data_as(C.POINTER(C.c_uint64))))
+        return out
+
+    @property
+    def states(self):
+        """model.states (0-based position k holds the reference's states[k+1])."""
+        return self.states_range(0, self.N)
+
+    def rank(self, states):
+        """0-based index of each state (reference idxmap value - 1), -1 when absent."""
+        st = np.ascontiguousarray(states, dtype=np.uint64).ravel()
+        out = np.empty(len(st), dtype=np.int64)
+        check(lib().sd_model_rank(self.h, st.ctypes.data_as(C.POINTER(C.c_uint64)), len(st),
+                                  out.ctypes.data_as(C.POINTER(C.c_int64))))
+        return out
+
+    @property
+    def device_path(self):
+        return "tiled" if lib().sd_model_path(self.h) == 1 else "generic"
+
+    # -- sharding --
+    def set_shard(self, rank, nranks):
+        check(lib().sd_model_set_shard(self.h, rank, nranks), self.ctx.h if self.ctx else None)
+
+    def shard_info(self):
+        info = _lib.sd_shard_info()
+        check(lib().sd_model_shard_info(self.h, C.byref(info)))
+        return info
+
+    def shard_slabs(self):
+        info = self.shard_info()
+        recv = (_lib.sd_slab * max(int(info.n_recv_slabs), 1))()
+        send = (_lib.sd_slab * max(int(info.n_send_slabs), 1))()
+        check(lib().sd_model_shard_slabs(self.h, recv, send))
+        r = [(s.peer, int(s.local_offset), int(s.count)) for s in recv[: int(info.n_recv_slabs)]]
+        s = [(s.peer, int(s.local_offset), int(s.count)) for s in send[: int(info.n_send_slabs)]]
+        return r, s
+
+
+def build_model(L, nup=None, hopping=(), onsite_field=None, zz=(), ctx="default"):
+    """build_model(L; nup, hopping, onsite_field, zz) -- src/SpinModel.jl:23-38"""
+    return Model(L, nup=nup, hopping=hopping, onsite_field=onsite_field, zz=zz, ctx=ctx)
+
+
+def nn_hopping(L, J):
+    """src/SpinModel.jl:40-42"""
+    return [(i, i + 1, float(J)) for i in range(1, L)]
+
+
+def long_range_hopping(L, J):
+    """src/SpinModel.jl:44-46 (J is a callable J(i, j))"""
+    return [(i, j, float(J(i, j))) for i in range(1, L + 1) for j in range(i + 1, L + 1)]
+
+
+def XXZChain(L, Jxy=1.0, Jz=1.0, hz=0.0, nup=None, boundary="open", ctx="default"):
+    """XXZChain(L; Jxy, Jz, hz, nup, boundary) -- src/SpinModel.jl:63-90"""
+    hopping = [(i, i + 1, float(Jxy) / 2) for i in range(1, L)]
+    zz = [(i, i + 1, float(Jz)) for i in range(1, L)]
+    if boundary == "periodic":
+        if L > 2:
+            hopping.append((L, 1, float(Jxy) / 2))
+            zz.append((L, 1, float(Jz)))
+    elif boundary != "open":
+        raise ArgumentError("boundary must be :open or :periodic")
+    return Model(L, nup=nup, hopping=hopping, onsite_field=np.full(max(L, 0), float(hz)), zz=zz, ctx=ctx)
+
+
+def momenta(model):
+    """q = 2*pi*n/L, n = 0..L-1 -- src/SpinModel.jl:97-99"""
+    return 2 * np.pi * np.arange(model.L) / model.L
