@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""Headline benchmark: H|psi> matvecs/s for XXZChain(L=32, nup=16) (ComplexF64, N = 601 080 390)
+on N MI355X GPUs of one node, the state sharded by basis-index range for N > 1.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path: out <- H psi on a random normalised psi resident in HBM (ping-pong
+between two buffers; for N > 1 each step includes the RCCL halo exchange).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X spec HBM3E peak (MI355X_MICROARCH.md); measured float4-copy ceiling 6290 GB/s
+SEED = 20260821
+
+
+def cpu_baseline(L, nup, budget_s=20.0):
+    """The C oracle (a port of the reference's algorithm: states[] + hash map, row-owner gather) timed on the
+    host cores on a bounded sample: the same model family at a smaller L, scaled to L=32 rows."""
+    import numpy as np
+    from oracle import oracle as O
+    from math import comb
+    Ls = int(os.environ.get("SD_BENCH_CPU_L", "24"))
+    t0 = time.time()
+    m = O.XXZChain(Ls, nup=Ls // 2)
+    build_s = time.time() - t0
+    rng = np.random.default_rng(1)
+    psi = rng.standard_normal(m.N) + 1j * rng.standard_normal(m.N)
+    O.apply_H(m, psi)  # warm
+    reps, t0 = 0, time.time()
+    while True:
+        O.apply_H(m, psi)
+        reps += 1
+        if time.time() - t0 > budget_s or reps >= 50:
+            break
+    dt = (time.time() - t0) / reps
+    rows_per_s = m.N / dt
+    n_full = comb(L, nup)
+    return {
+        "value": rows_per_s / n_full,
+        "unit": "matvecs/s (L=32-equivalent, rows/s scaled by N)",
+        "cores": O.num_threads(),
+        "kind": "port",
+        "sample": f"oracle so_apply_H, XXZChain(L={Ls},nup={Ls // 2}) c128, N={m.N}, {reps} applies, "
+                  f"{dt * 1e3:.1f} ms each ({rows_per_s / 1e6:.1f} Mrows/s); basis+hash build {build_s:.1f} s; "
+                  f"extrapolated proportional to N (optimistic for the CPU: its hash map leaves cache at L=32)",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--L", type=int, default=int(os.environ.get("SD_BENCH_L", "32")))
+    ap.add_argument("--dtype", default="c128", choices=["c128", "f64"])
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import __graft_entry__ as g
+    pkg = g.load_package()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    L, nup = args.L, args.L // 2
+    tdtype = torch.complex128 if args.dtype == "c128" else torch.float64
+    esize = 16 if args.dtype == "c128" else 8
+    model = pkg.XXZChain(L, nup=nup)
+    op = pkg.ShardedOperator(model, rank, world)
+    a = op.empty(tdtype, dev)
+    b = op.empty(tdtype, dev)
+    op.fill_randn(a, SEED)
+    nrm = op.norm(a)
+    a[: op.n_local] /= nrm
+    b.zero_()
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    src, dst = a, b
+    for _ in range(args.warmup):
+        op.apply(dst, src)
+        src, dst = dst, src
+    sync()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        op.apply(dst, src)
+        src, dst = dst, src
+    ev1.record()
+    sync()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ev_ms = ev0.elapsed_time(ev1) / args.steps  # per step, device time on the launch stream
+
+    # kernel-only timing (no exchange) for the roofline of the dominant kernel: HIP events around K launches
+    kern_ms = ev_ms
+    if world > 1:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.steps):
+            op.apply(dst, src, exchange=False)
+            src, dst = dst, src
+        e1.record()
+        torch.cuda.synchronize()
+        kern_ms = e0.elapsed_time(e1) / args.steps
+
+    if rank == 0:
+        N = model.N
+        ms_per_step = elapsed / args.steps * 1e3
+        alg_bytes = op.n_local * 2 * esize               # read psi[idx] once + write out[idx] once
+        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9    # GB/s on this rank's GPU
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tp):
+            try:
+                tj = json.load(open(tp))
+                if tj.get("L") == L and tj.get("dtype") == args.dtype and world == 1:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "H|psi> matvecs/s, XXZ L=%d Sz=0" % L,
+            "value": args.steps / elapsed,
+            "unit": "matvecs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": args.dtype,
+            "data": "synthetic: counter-based N(0,1) psi keyed by (seed=%d, global index), normalised" % SEED,
+            "config": {"workload": "XXZChain(L=%d, nup=%d) open, Jxy=Jz=1, hz=0: out <- H psi, ComplexF64, N=%d; "
+                                   "basis-index-range shards, %d rank(s), halo exchange per step" % (L, nup, N, world),
+                       "rows_per_rank": op.n_local, "halo_rows_rank0": op.n_halo,
+                       "device_path": model.device_path},
+            "achieved_hbm_GBs_per_gpu": achieved,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "k_apply_tiled<c128>" if args.dtype == "c128" else "k_apply_tiled<f64>",
+                         "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes},
+        }
+        if world == 1 and not args.no_cpu:
+            try:
+                line["cpu_baseline"] = cpu_baseline(L, nup)
+            except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
+                line["cpu_baseline"] = {"value": None, "unit": "matvecs/s", "cores": 0, "kind": "port",
+                                        "sample": "failed: %r" % (e,)}
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

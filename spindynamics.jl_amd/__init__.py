@@ -15,5 +15,6 @@ from .solvers import (chebyshev_coeffs, chebyshev_time_evolve, compute_chebyshev
                       lanczos_extremal, lanczos_groundstate, lanczos_sqw, lanczos_tridiag, rescaling_from_bounds,
                       spectral_from_tridiagonal, symtridiag_eig)
 from .api import dynamical_structure_factor, groundstate, time_evolve
+from .dist import ShardedOperator
 
 __all__ = [n for n in dir() if not n.startswith("_")]

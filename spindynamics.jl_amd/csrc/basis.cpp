@@ -74,10 +74,10 @@ static void enum_sector(int n, int t, std::vector<uint16_t> &out) {
 }
 
 static int suffix_bits_from_env() {
-  int ls = 14;
+  int ls = 13;
   if (const char *e = getenv("SD_SUFFIX_BITS")) ls = atoi(e);
   if (ls < 2) ls = 2;
-  if (ls > 16) ls = 16;
+  if (ls > 15) ls = 15;
   return ls;
 }
 
@@ -203,6 +203,29 @@ int sd_build_plan(sd_model *m, int rank, int nranks, std::string &err) {
     m->max_tile_len = std::max<int>(m->max_tile_len, (int)B(m, LS, t2));
   }
 
+  // XCD-aware processing order.  Workgroups are dealt round-robin over the 8 XCDs (block b -> XCD b % 8), each with
+  // a private 4 MiB L2.  Give every XCD runs of CH consecutive tiles so that the near prefix bonds (partner tile a few
+  // tiles away) hit in that XCD's L2.  Affects speed only: the mapping is a bijection of the local tile list.
+  {
+    int CH = 32;
+    if (const char *e = getenv("SD_XCD_CHUNK")) CH = atoi(e);
+    const size_t nt = m->tile_prefix.size();
+    if (CH > 0 && nt >= (size_t)16 * CH) {
+      std::vector<uint32_t> tp(nt);
+      std::vector<int64_t> tb(nt);
+      const size_t group = (size_t)8 * CH, full = nt / group * group;
+      for (size_t b = 0; b < nt; ++b) {
+        size_t t = b;
+        if (b < full) {
+          const size_t x = b % 8, sl = b / 8, g = sl / CH, i = sl % CH;
+          t = g * group + x * CH + i;
+        }
+        tp[b] = m->tile_prefix[t]; tb[b] = m->tile_base[t];
+      }
+      m->tile_prefix.swap(tp); m->tile_base.swap(tb);
+    }
+  }
+
   if (nranks > 1) {
     const int nn = count_nn_hops(m);
     std::vector<uint8_t> need(nP);
@@ -303,6 +326,13 @@ int sd_upload_model(sd_model *m, std::string &err) {
     }
   }
   if (getenv("SD_EXACT_DIAG")) d.diag_mode = 0;
+  m->hop_pow2 = true;
+  for (int k = 0; k < d.nn_hops; ++k) {
+    int ex; const double mant = std::frexp(m->hop_J[k], &ex);
+    if (!(m->hop_J[k] == 0.0 || std::fabs(mant) == 0.5) || !std::isfinite(m->hop_J[k])) m->hop_pow2 = false;
+  }
+  if (getenv("SD_NO_FMA")) m->hop_pow2 = false;
+  d.dbg = getenv("SD_DEBUG_SKIP") ? atoi(getenv("SD_DEBUG_SKIP")) : 0;
   int rc;
   if ((rc = up(m, m->hop_i, &d.hop_i, err))) return rc;
   if ((rc = up(m, m->hop_j, &d.hop_j, err))) return rc;

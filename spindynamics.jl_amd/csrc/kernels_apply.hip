@@ -22,7 +22,6 @@
 #include "sd_internal.hpp"
 
 #define SD_BIN_STRIDE 17
-#define SD_ROWS_PER_THREAD 8
 
 namespace {
 
@@ -200,19 +199,54 @@ __device__ __forceinline__ bool epi_has_sums(int epi) {
 // =====================================================================
 // tiled kernel
 // =====================================================================
-template <int NC>
-__global__ __launch_bounds__(1024) void k_apply_tiled(sd_dev_model dm, double *__restrict__ out_,
-                                                      const double *__restrict__ psi_, int epi, sd_epi_args ea,
-                                                      double *__restrict__ partials, int max_len) {
+//
+// One workgroup per tile (prefix configuration P).  Each thread owns R rows
+// i = tid + r*BLOCK of the tile.
+//   1. own rows + suffix configurations are requested from HBM;
+//   2. every wave builds, in its own registers (lane b-1 <-> prefix bond b, lane
+//      p-1 <-> the straddling bond), the list of flippable far bonds with the
+//      partner tile's base offset -- no LDS, no barrier, one memory latency;
+//   3. the far-bond partner rows are streamed with a two-deep ping-pong
+//      pipeline (loads of bond k+1 in flight while bond k is accumulated);
+//   4. own rows go to LDS, barrier, then the suffix bonds are LDS reads at
+//      idx +- C(LS-a-1,u);
+//   5. fused epilogue + store.
+// Accumulation order per row is the reference's bond order 1..L-1.  When every
+// NN hop amplitude is a power of two (XXZChain default 0.5) J*psi is exact and
+// acc + J*psi is evaluated with one fma (bit-identical to the unfused form).
+template <bool FMA>
+__device__ __forceinline__ double acc1(double acc, double J, double v) {
+  return FMA ? __builtin_fma(J, v, acc) : acc + J * v;
+}
+template <bool FMA>
+__device__ __forceinline__ double accum(double acc, double J, double v) { return acc1<FMA>(acc, J, v); }
+template <bool FMA>
+__device__ __forceinline__ double2 accum(double2 acc, double J, double2 v) {
+  return make_double2(acc1<FMA>(acc.x, J, v.x), acc1<FMA>(acc.y, J, v.y));
+}
+
+__device__ __forceinline__ int rl(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+__device__ __forceinline__ int64_t rl64(int64_t v, int lane) {
+  const uint32_t lo = (uint32_t)rl((int)(uint32_t)v, lane), hi = (uint32_t)rl((int)(uint32_t)((uint64_t)v >> 32), lane);
+  return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ double rld(double v, int lane) { return __longlong_as_double(rl64(__double_as_longlong(v), lane)); }
+
+struct FarBond { int64_t base; double J; int lo, hi, shift; };
+
+template <int NC, int R, int BLOCK, bool FMA>
+__global__ __launch_bounds__(BLOCK) void k_apply_tiled(sd_dev_model dm, double *__restrict__ out_,
+                                                       const double *__restrict__ psi_, int epi, sd_epi_args ea,
+                                                       double *__restrict__ partials, int max_len) {
   using V = typename VT<NC>::type;
-  constexpr int R = SD_ROWS_PER_THREAD;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   V *tile = reinterpret_cast<V *>(smem);
   int *lbin = reinterpret_cast<int *>(smem + (size_t)max_len * sizeof(V));
   double *red = reinterpret_cast<double *>(lbin + 16 * SD_BIN_STRIDE);
 
   const V *__restrict__ psi = reinterpret_cast<const V *>(psi_);
-  const int tid = threadIdx.x, BS = blockDim.x;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
   const int tix = blockIdx.x;
   const uint32_t P = dm.tile_prefix[tix];
   const int64_t base = dm.tile_base[tix];
@@ -221,80 +255,108 @@ __global__ __launch_bounds__(1024) void k_apply_tiled(sd_dev_model dm, double *_
   const int len = (int)binom_g(dm, LS, t2);
   const int nU = (int)binom_g(dm, LS - 1, t2 - 1);  // rows whose first suffix site is up
   const uint16_t *__restrict__ sufS = dm.suf_states + dm.suf_off[t2];
+  const int nn = dm.nn_hops;
 
-  // ---- stage: own rows -> registers + LDS, suffix configurations, binomials ----
+  // ---- 1. request own rows and suffix configurations ----
+  V own[R];
   uint32_t sig[R];
   int irow[R];
-  {
-    V own[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int i = tid + r * BLOCK;
+    irow[r] = i < len ? i : len - 1;
+    own[r] = psi[base + irow[r]];
+    sig[r] = sufS[irow[r]];
+  }
+
+  // ---- 2. per-wave list of flippable far bonds (lane b-1 <-> bond b <= p-1, lane p-1 <-> straddle) ----
+  uint64_t fmask = 0;
+  int64_t my_base = 0;
+  double my_J = 0.0;
+  int my_lo = 0, my_hi = len, my_shift = 0;
+  if (nn > 0 && p >= 1) {
+    bool fl = false;
+    const int b = lane + 1;
+    if (b <= p - 1) {
+      fl = (((P >> (b - 1)) ^ (P >> b)) & 1u) && !(dm.dbg & 1);
+      if (fl) { my_base = dm.addr[P ^ (3u << (b - 1))]; my_J = dm.hop_J[b - 1]; }
+    } else if (b == p) {
+      // bit p of P up: our rows with first suffix site down (i >= nU) <-> partner rows i - nU
+      // bit p of P down: our rows with first suffix site up (i < nU)  <-> partner rows nUq + i
+      const uint32_t bitp = (P >> (p - 1)) & 1u;
+      const uint32_t Q = P ^ (1u << (p - 1));
+      const int t2q = dm.nup - __popc(Q);
+      if (t2q >= 0 && t2q <= LS && !(dm.dbg & 2)) {
+        const int nUq = (int)binom_g(dm, LS - 1, t2q - 1);
+        if (bitp) { my_lo = nU; my_hi = len; my_shift = -nU; }
+        else { my_lo = 0; my_hi = nU; my_shift = nUq; }
+        fl = my_hi > my_lo;
+        if (fl) { my_base = dm.addr[Q]; my_J = dm.hop_J[p - 1]; }
+      }
+    }
+    fmask = __ballot(fl);
+  }
+
+  auto get_bond = [&](int ln) {
+    FarBond fb;
+    fb.base = rl64(my_base, ln); fb.J = rld(my_J, ln);
+    fb.lo = rl(my_lo, ln); fb.hi = rl(my_hi, ln); fb.shift = rl(my_shift, ln);
+    return fb;
+  };
+  auto issue = [&](const FarBond &fb, V(&v)[R]) {
+    const V *__restrict__ src = psi + fb.base;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const int i = tid + r * BS;
-      const int ic = i < len ? i : len - 1;
-      irow[r] = ic;
-      own[r] = psi[base + ic];
-      sig[r] = sufS[ic];
+      const int i = irow[r];
+      const bool in = (i >= fb.lo) && (i < fb.hi);
+      v[r] = src[in ? i + fb.shift : 0];
     }
-#pragma unroll
-    for (int r = 0; r < R; ++r)
-      if (tid + r * BS < len) tile[irow[r]] = own[r];
-  }
-  for (int k = tid; k < 16 * SD_BIN_STRIDE; k += BS) {
-    int n = k / SD_BIN_STRIDE, kk = k - n * SD_BIN_STRIDE;
-    lbin[k] = (int)binom_g(dm, n, kk);
-  }
-  __syncthreads();
+  };
 
-  // ---- diagonal ----
+  // first far bond in flight before the own rows have even arrived
+  V va[R], vb[R];
+  FarBond fa{}, fbb{};
+  uint64_t mk = fmask;
+  bool have_a = false;
+  if (mk) { fa = get_bond(__builtin_ctzll(mk)); mk &= mk - 1; issue(fa, va); have_a = true; }
+
+  // ---- diagonal (needs own) ----
   V acc[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const uint64_t s = (uint64_t)P | ((uint64_t)sig[r] << p);
-    acc[r] = vscale(diag_of(dm, s), tile[irow[r]]);
+    acc[r] = vscale(diag_of(dm, s), own[r]);
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+    if (tid + r * BLOCK < len) tile[irow[r]] = own[r];
+  for (int k = tid; k < 16 * SD_BIN_STRIDE; k += BLOCK) {
+    int n = k / SD_BIN_STRIDE, kk = k - n * SD_BIN_STRIDE;
+    lbin[k] = (int)binom_g(dm, n, kk);
   }
 
-  const int nn = dm.nn_hops;
-  if (nn > 0) {
-    // ---- bonds inside the prefix: whole-tile streams (wave-uniform control flow) ----
-    for (int b = 1; b <= p - 1; ++b) {
-      if (((P >> (b - 1)) ^ (P >> b)) & 1u) {
-        const int64_t qb = dm.addr[P ^ (3u << (b - 1))];
-        const double J = dm.hop_J[b - 1];
-        const V *__restrict__ src = psi + qb;
-        V v[R];
+  // ---- 3. far bonds: ping-pong pipeline, accumulation in bond order ----
+  while (have_a) {
+    bool have_b = false;
+    if (mk) { fbb = get_bond(__builtin_ctzll(mk)); mk &= mk - 1; issue(fbb, vb); have_b = true; }
 #pragma unroll
-        for (int r = 0; r < R; ++r) v[r] = src[irow[r]];
-#pragma unroll
-        for (int r = 0; r < R; ++r) acc[r] = vadd_mul(acc[r], J, v[r]);
-      }
+    for (int r = 0; r < R; ++r) {
+      const int i = irow[r];
+      if (i >= fa.lo && i < fa.hi) acc[r] = accum<FMA>(acc[r], fa.J, va[r]);
     }
-    // ---- the bond straddling prefix | suffix: half-tile stream ----
-    if (p >= 1) {
-      const uint32_t bitp = (P >> (p - 1)) & 1u;
-      const uint32_t Q = P ^ (1u << (p - 1));
-      const int t2q = dm.nup - __popc(Q);
-      if (t2q >= 0 && t2q <= LS) {
-        const int64_t qb = dm.addr[Q];
-        const double J = dm.hop_J[p - 1];
-        const V *__restrict__ src = psi + qb;
-        // bitp = 1: our rows with first suffix site down (i >= nU) <-> partner rows i - nU
-        // bitp = 0: our rows with first suffix site up   (i <  nU) <-> partner rows nUq + i
-        const int nUq = (int)binom_g(dm, LS - 1, t2q - 1);
-        V v[R];
-        bool fl[R];
+    have_a = false;
+    if (!have_b) break;
+    if (mk) { fa = get_bond(__builtin_ctzll(mk)); mk &= mk - 1; issue(fa, va); have_a = true; }
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-          const int i = irow[r];
-          fl[r] = bitp ? (i >= nU) : (i < nU);
-          const int ip = bitp ? (i - nU) : (nUq + i);
-          v[r] = src[fl[r] ? ip : 0];
-        }
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-          if (fl[r]) acc[r] = vadd_mul(acc[r], J, v[r]);
-      }
+    for (int r = 0; r < R; ++r) {
+      const int i = irow[r];
+      if (i >= fbb.lo && i < fbb.hi) acc[r] = accum<FMA>(acc[r], fbb.J, vb[r]);
     }
-    // ---- bonds inside the suffix: LDS reads at idx +- C(LS-a-1, u) ----
+  }
+  __syncthreads();
+
+  // ---- 4. bonds inside the suffix: LDS reads at idx +- C(LS-a-1, u) ----
+  if (nn > 0 && !(dm.dbg & 4)) {
     for (int a = 1; a <= LS - 1; ++a) {
       const double J = dm.hop_J[p + a - 1];
       const int *brow = lbin + (LS - a - 1) * SD_BIN_STRIDE;
@@ -306,7 +368,7 @@ __global__ __launch_bounds__(1024) void k_apply_tiled(sd_dev_model dm, double *_
           const int u = __popc(sg >> (a + 1));
           const int d = brow[u];
           const int ip = ba ? irow[r] + d : irow[r] - d;
-          acc[r] = vadd_mul(acc[r], J, tile[ip]);
+          acc[r] = accum<FMA>(acc[r], J, tile[ip]);
         }
       }
     }
@@ -323,17 +385,17 @@ __global__ __launch_bounds__(1024) void k_apply_tiled(sd_dev_model dm, double *_
         if (((s >> bi) ^ (s >> bj)) & 1) {
           const uint64_t s2 = s ^ ((uint64_t)1 << bi) ^ ((uint64_t)1 << bj);
           const int64_t idx = dm.addr[(uint32_t)(s2 & pmask)] + dm.suf_rank[(uint32_t)(s2 >> p)];
-          acc[r] = vadd_mul(acc[r], J, psi[idx]);
+          acc[r] = accum<false>(acc[r], J, psi[idx]);
         }
       }
     }
   }
 
-  // ---- epilogue + store ----
+  // ---- 5. epilogue + store ----
   EpiSums sums{0.0, 0.0};
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    const int i = tid + r * BS;
+    const int i = tid + r * BLOCK;
     if (i < len) epilogue<NC>(epi, ea, base + i, acc[r], tile[i], out_, sums);
   }
   if (epi_has_sums(epi)) {
@@ -443,10 +505,29 @@ int ensure_partials(sd_ctx *ctx, size_t doubles) {
   return SD_OK;
 }
 
-int block_for_len(int max_len) {
-  int bs = 64;
-  while (bs < 1024 && bs * SD_ROWS_PER_THREAD < max_len) bs <<= 1;
-  return bs;
+template <int NC, int R, int BLOCK, bool FMA>
+int launch_tiled_cfg(sd_ctx *ctx, const sd_dev_model &dm, int nt, size_t shmem, double *out, const double *psi, int epi,
+                     const sd_epi_args &ea, int max_len) {
+  auto kern = k_apply_tiled<NC, R, BLOCK, FMA>;
+  static size_t attr_set = 0;
+  if (shmem > 48 * 1024 && shmem > attr_set) {
+    SD_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    attr_set = shmem;
+  }
+  hipLaunchKernelGGL(kern, dim3(nt), dim3(BLOCK), shmem, ctx->stream, dm, out, psi, epi, ea, ctx->d_partials, max_len);
+  SD_HIP(ctx, hipGetLastError());
+  return SD_OK;
+}
+
+template <int NC, bool FMA>
+int launch_tiled(sd_ctx *ctx, const sd_dev_model &dm, int nt, size_t shmem, double *out, const double *psi, int epi,
+                 const sd_epi_args &ea, int max_len) {
+  // rows per thread: 4 for ComplexF64, 8 for Float64 (same register footprint); smallest block that covers a tile
+  constexpr int R = NC == 2 ? 4 : 8;
+  if (max_len <= 256 * R) return launch_tiled_cfg<NC, R, 256, FMA>(ctx, dm, nt, shmem, out, psi, epi, ea, max_len);
+  if (max_len <= 512 * R) return launch_tiled_cfg<NC, R, 512, FMA>(ctx, dm, nt, shmem, out, psi, epi, ea, max_len);
+  if (max_len <= 1024 * R) return launch_tiled_cfg<NC, R, 1024, FMA>(ctx, dm, nt, shmem, out, psi, epi, ea, max_len);
+  return sd_set_err(ctx, SD_EINTERNAL, "tile longer than a workgroup can hold");
 }
 
 }  // namespace
@@ -462,21 +543,16 @@ int sd_launch_apply(sd_ctx *ctx, const sd_model *m, int dtype, void *out, const 
     const int nt = dm.n_tiles;
     if (sums) { int rc = ensure_partials(ctx, 2 * (size_t)nt); if (rc) return rc; }
     const int max_len = m->max_tile_len;
-    if (max_len > 1024 * SD_ROWS_PER_THREAD) return sd_set_err(ctx, SD_EINTERNAL, "tile longer than a workgroup can hold");
-    const int bs = block_for_len(max_len);
     const size_t esz = dtype == SD_C128 ? 16 : 8;
     const size_t shmem = (size_t)max_len * esz + 16 * SD_BIN_STRIDE * sizeof(int) + 32 * sizeof(double) + 16;
-    if (dtype == SD_C128) {
-      if (shmem > 48 * 1024)
-        SD_HIP(ctx, hipFuncSetAttribute((const void *)k_apply_tiled<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-      hipLaunchKernelGGL(k_apply_tiled<2>, dim3(nt), dim3(bs), shmem, ctx->stream, dm, (double *)out,
-                         (const double *)psi, epi, ea, ctx->d_partials, max_len);
-    } else {
-      if (shmem > 48 * 1024)
-        SD_HIP(ctx, hipFuncSetAttribute((const void *)k_apply_tiled<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-      hipLaunchKernelGGL(k_apply_tiled<1>, dim3(nt), dim3(bs), shmem, ctx->stream, dm, (double *)out,
-                         (const double *)psi, epi, ea, ctx->d_partials, max_len);
-    }
+    int rc;
+    if (dtype == SD_C128)
+      rc = m->hop_pow2 ? launch_tiled<2, true>(ctx, dm, nt, shmem, (double *)out, (const double *)psi, epi, ea, max_len)
+                       : launch_tiled<2, false>(ctx, dm, nt, shmem, (double *)out, (const double *)psi, epi, ea, max_len);
+    else
+      rc = m->hop_pow2 ? launch_tiled<1, true>(ctx, dm, nt, shmem, (double *)out, (const double *)psi, epi, ea, max_len)
+                       : launch_tiled<1, false>(ctx, dm, nt, shmem, (double *)out, (const double *)psi, epi, ea, max_len);
+    if (rc) return rc;
     SD_HIP(ctx, hipGetLastError());
     if (sums) {
       hipLaunchKernelGGL(k_reduce_pairs, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_partials, (int64_t)nt, ctx->d_scalars);

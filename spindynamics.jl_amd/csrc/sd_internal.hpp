@@ -53,6 +53,7 @@ struct sd_dev_model {
   double diag_q;         // Jz/4 for diag_mode 1
   int n_zz_nn;           // leading zz bonds that are the NN chain in order (L-1 or 0), for diag_mode 1
   int field_zero;
+  int dbg;               // timing-only ablation bits from env SD_DEBUG_SKIP (1 prefix bonds, 2 straddle, 4 suffix bonds)
   int64_t N;             // global dimension
   int64_t n_local;       // rows owned by this shard (== N unsharded)
   int64_t row_lo;        // first owned global row
@@ -90,6 +91,7 @@ struct sd_model {
   std::vector<int32_t> suf_off;
   std::vector<sd_slab> recv_slabs, send_slabs;
   int max_tile_len = 0;
+  bool hop_pow2 = false;  // every NN hop amplitude is +-2^k (or 0): J*psi is exact, fma == mul+add
   // device copies
   sd_dev_model dm{};
   std::vector<void *> dev_allocs;
