@@ -207,6 +207,7 @@ typedef struct sd_slab {
   int peer;                 /* rank on the other side */
   int64_t local_offset;     /* element offset in THIS rank's vector (send: within owned rows; recv: >= n_local) */
   int64_t count;            /* elements */
+  int64_t global_row;       /* global basis index of the slab's first element */
 } sd_slab;
 /* Re-plans the model as shard `rank` of `nranks` (nranks == 1 restores the
  * unsharded plan).  Must be called before any apply on that model. */

@@ -6,6 +6,7 @@ raises (SD_ENODEV).
 """
 import ctypes as C
 import os
+import sys
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libspindyn.so")
@@ -41,7 +42,7 @@ class sd_shard_info(C.Structure):
 
 
 class sd_slab(C.Structure):
-    _fields_ = [("peer", C.c_int), ("local_offset", C.c_int64), ("count", C.c_int64)]
+    _fields_ = [("peer", C.c_int), ("local_offset", C.c_int64), ("count", C.c_int64), ("global_row", C.c_int64)]
 
 
 _vp, _i, _i64, _u64, _d = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_double
@@ -107,6 +108,14 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc, gfx950).  There is no CPU fallback.")
+        # PyTorch-ROCm wheels bundle their own HIP/HSA runtime under the same sonames as /opt/rocm.  Two HIP
+        # runtimes cannot share a process, so when torch is installed let it load first: libspindyn then binds
+        # to the runtime torch brought (device tensors from torch are usable either way).
+        if "torch" not in sys.modules and not os.environ.get("SD_NO_TORCH_PRELOAD"):
+            try:
+                import torch  # noqa: F401
+            except Exception:
+                pass
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(l, name)

@@ -234,7 +234,7 @@ int sd_build_plan(sd_model *m, int rank, int nranks, std::string &err) {
       collect_needs(m, tiles, kb[q], kb[q + 1], nn, need);
       // walk all tiles in global order; tiles needed by q and owned by someone else form q's halo
       int64_t halo_off = row_of(kb[q + 1]) - row_of(kb[q]);  // q's n_local
-      sd_slab cur{-1, 0, 0};
+      sd_slab cur{-1, 0, 0, 0};
       int64_t cur_end_global = -1;
       auto flush = [&]() {
         if (cur.count == 0) return;
@@ -250,7 +250,7 @@ int sd_build_plan(sd_model *m, int rank, int nranks, std::string &err) {
         if (q == rank) {
           m->addr[tiles[k].P] = halo_off;
           if (cur.count > 0 && cur.peer == own && cur_end_global == tiles[k].base) cur.count += len;
-          else { flush(); cur = {own, halo_off, len}; }
+          else { flush(); cur = {own, halo_off, len, tiles[k].base}; }
           cur_end_global = tiles[k].base + len;
         } else if (own == rank) {
           // q needs one of my tiles: a send slab (merged exactly like q merges its receives)
@@ -258,7 +258,7 @@ int sd_build_plan(sd_model *m, int rank, int nranks, std::string &err) {
           if (!m->send_slabs.empty() && m->send_slabs.back().peer == q &&
               m->send_slabs.back().local_offset + m->send_slabs.back().count == loc)
             m->send_slabs.back().count += len;
-          else m->send_slabs.push_back({q, loc, len});
+          else m->send_slabs.push_back({q, loc, len, tiles[k].base});
         }
         halo_off += len;
       }

@@ -41,9 +41,9 @@ class ShardedOperator:
         import torch.distributed as dist
         flat = torch.view_as_real(psi) if psi.is_complex() else psi
         ops = []
-        for (peer, off, cnt) in self.recv_slabs:
+        for (peer, off, cnt, _g) in self.recv_slabs:
             ops.append(dist.P2POp(dist.irecv, flat[off:off + cnt], peer, group))
-        for (peer, off, cnt) in self.send_slabs:
+        for (peer, off, cnt, _g) in self.send_slabs:
             ops.append(dist.P2POp(dist.isend, flat[off:off + cnt], peer, group))
         if ops:
             for req in dist.batch_isend_irecv(ops):
@@ -54,6 +54,8 @@ class ShardedOperator:
         import torch
         if exchange:
             self.exchange(psi, group)
+        if self.n_local == 0:      # a rank may own no tile when there are fewer tiles than ranks
+            return out
         m = self.model
         m.ctx.set_stream(torch.cuda.current_stream(psi.device).cuda_stream)
         code = _lib.SD_C128 if psi.is_complex() else _lib.SD_F64
@@ -63,6 +65,8 @@ class ShardedOperator:
     def cheb_step(self, phi_next, phi_curr, phi_prev, psi_t, a, b, c, group=None):
         import torch
         self.exchange(phi_curr, group)
+        if self.n_local == 0:
+            return phi_next
         m = self.model
         m.ctx.set_stream(torch.cuda.current_stream(phi_curr.device).cuda_stream)
         c = complex(c)
@@ -73,6 +77,8 @@ class ShardedOperator:
     def fill_randn(self, x, seed):
         """Counter-based N(0,1) keyed by the GLOBAL element index: identical for every sharding."""
         import torch
+        if self.n_local == 0:
+            return x
         m = self.model
         m.ctx.set_stream(torch.cuda.current_stream(x.device).cuda_stream)
         per = 2 if x.is_complex() else 1

@@ -96,8 +96,8 @@ class Model:
         recv = (_lib.sd_slab * max(int(info.n_recv_slabs), 1))()
         send = (_lib.sd_slab * max(int(info.n_send_slabs), 1))()
         check(lib().sd_model_shard_slabs(self.h, recv, send))
-        r = [(s.peer, int(s.local_offset), int(s.count)) for s in recv[: int(info.n_recv_slabs)]]
-        s = [(s.peer, int(s.local_offset), int(s.count)) for s in send[: int(info.n_send_slabs)]]
+        r = [(s.peer, int(s.local_offset), int(s.count), int(s.global_row)) for s in recv[: int(info.n_recv_slabs)]]
+        s = [(s.peer, int(s.local_offset), int(s.count), int(s.global_row)) for s in send[: int(info.n_send_slabs)]]
         return r, s
 
 

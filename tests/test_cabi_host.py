@@ -1,0 +1,171 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol include/spindyn.h declares, refuses to
+run without a GPU (no CPU fallback), and its host-only entry points (basis queries, small host numerics, shard
+plans) agree with the oracle.  No device compute is called here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "spindyn.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(sd_[A-Za-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    lib = C.CDLL(pkg.LIB_PATH)
+    names = header_functions()
+    assert len(names) >= 40
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/spindyn.h but not exported"
+    # the ctypes prototype table covers the header exactly
+    assert set(pkg.PROTOTYPES) == set(names)
+
+
+def test_no_cpu_fallback(pkg):
+    l = pkg.lib()
+    if l.sd_device_count() > 0:
+        pytest.skip("a GPU is present")
+    h = C.c_void_p()
+    assert l.sd_ctx_create(0, C.byref(h)) == 6  # SD_ENODEV
+    with pytest.raises(pkg.SpinDynError):
+        pkg.XXZChain(4, nup=2)
+
+
+def test_product_does_not_import_oracle():
+    pk = os.path.join(ROOT, "spindynamics.jl_amd")
+    for dirpath, _, files in os.walk(pk):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in txt.replace("the CPU oracle", "").replace("bit-identical to the CPU", ""), f
+
+
+@pytest.mark.parametrize("L,nup", [(4, 2), (8, 3), (12, 6), (15, 7), (16, 8), (18, 4), (20, 10), (7, 0), (7, 7), (6, None)])
+def test_host_basis_matches_oracle(pkg, O, L, nup):
+    m = pkg.XXZChain(L, nup=nup, ctx=None)
+    r = O.XXZChain(L, nup=nup)
+    st = r.states
+    assert m.N == r.N
+    assert np.array_equal(m.states, st)
+    assert np.array_equal(m.rank(st), np.arange(m.N))
+    bad = np.array([(1 << L) | 1, (1 << L) - 1 if nup not in (None, L) else 1 << L], dtype=np.uint64)
+    assert (m.rank(bad) == -1).all()
+
+
+def test_large_L_index_closed_form(pkg):
+    # 64-bit indices: L=36 nup=18 has 9 075 135 300 rows (> 2^32); first/last states and a rank/unrank round trip
+    m = pkg.XXZChain(36, nup=18, ctx=None)
+    assert m.N == 9075135300
+    assert int(m.states_range(0, 1)[0]) == (1 << 18) - 1
+    assert int(m.states_range(m.N - 1, 1)[0]) == ((1 << 18) - 1) << 18
+    rng = np.random.default_rng(0)
+    idx = rng.integers(0, m.N, 2000)
+    st = np.array([m.states_range(int(i), 1)[0] for i in idx], dtype=np.uint64)
+    assert all(bin(int(s)).count("1") == 18 for s in st)
+    assert np.array_equal(m.rank(st), idx)
+    # neighbouring indices are ordered lexicographically over site lists (ascending bit-reversed value)
+    s2 = m.states_range(123456789, 3)
+    key = [tuple(i for i in range(36) if (int(s) >> i) & 1) for s in s2]
+    assert key == sorted(key)
+
+
+def test_argument_validation(pkg):
+    for kw in [dict(L=0, nup=0), dict(L=64, nup=1), dict(L=4, nup=5), dict(L=4, nup=-3)]:
+        with pytest.raises(pkg.ArgumentError):
+            pkg.XXZChain(kw["L"], nup=kw["nup"], ctx=None)
+    with pytest.raises(pkg.ArgumentError):
+        pkg.XXZChain(4, nup=2, boundary="twisted", ctx=None)
+    with pytest.raises(pkg.ArgumentError):
+        pkg.build_model(4, nup=2, hopping=[(1, 5, 1.0)], ctx=None)
+    with pytest.raises(pkg.ArgumentError):
+        pkg.groundstate(pkg.XXZChain(4, nup=2, ctx=None), method="unknown")
+    with pytest.raises(pkg.ArgumentError):
+        pkg.time_evolve(pkg.XXZChain(4, nup=2, ctx=None), np.zeros(6, complex), 0.1, method="unknown")
+    with pytest.raises(pkg.ArgumentError):
+        pkg.dynamical_structure_factor(pkg.XXZChain(4, nup=2, ctx=None), np.zeros(6), [0.0], [0.0], method="unknown")
+
+
+def test_host_numerics_match_oracle(pkg, O):
+    rng = np.random.default_rng(1)
+    for n in (1, 2, 7, 40, 100):
+        d, e = rng.standard_normal(n), rng.standard_normal(max(n - 1, 0))
+        w, z = pkg.symtridiag_eig(d, e)
+        T = np.diag(d) + np.diag(e, 1) + np.diag(e, -1)
+        assert np.abs(w - np.linalg.eigvalsh(T)).max() <= 1e-12
+        assert np.abs(T @ z - z * w).max() <= 1e-12
+    assert np.abs(pkg.chebyshev_coeffs(50, 2.7, -0.3, 0.8) - O.chebyshev_coeffs(50, 2.7, -0.3, 0.8)).max() <= 1e-15
+    for kern in ("jackson", "lorentz", "none"):
+        assert np.array_equal(pkg.get_kernel(33, kern), O.get_kernel(33, kern))
+    assert pkg.rescaling_from_bounds(-3.0, 5.0) == O.rescaling_from_bounds(-3.0, 5.0)
+    mu = rng.standard_normal(30) * 0.1
+    om = np.linspace(-1, 4, 57)
+    assert np.array_equal(pkg.kpm_reconstruct(mu, om, 3.1, 0.2, -2.0), O.kpm_reconstruct(mu, om, 3.1, 0.2, -2.0))
+    al, be = rng.standard_normal(12), rng.standard_normal(11)
+    for br in ("lorentz", "gauss"):
+        got = pkg.spectral_from_tridiagonal(al, be, 1.3, -0.5, om, eta=0.07, broaden=br)
+        assert np.abs(got - O.spectral_from_tridiagonal(al, be, 1.3, -0.5, om, eta=0.07, broaden=br)).max() <= 1e-12
+    with pytest.raises(pkg.ArgumentError):
+        pkg.spectral_from_tridiagonal(al, be, 1.0, 0.0, om, broaden="box")
+
+
+def test_randn_host_stream(pkg):
+    x = np.empty(100000)
+    y = np.empty(1000)
+    l = pkg.lib()
+    dp = C.POINTER(C.c_double)
+    assert l.sd_fill_randn_host(x.ctypes.data_as(dp), len(x), 20260821, 0) == 0
+    assert l.sd_fill_randn_host(y.ctypes.data_as(dp), len(y), 20260821, 5000) == 0
+    assert np.array_equal(x[5000:6000], y)            # keyed by the global element index
+    assert abs(x.mean()) < 0.02 and abs(x.std() - 1) < 0.02
+
+
+@pytest.mark.parametrize("L,nup,P", [(12, 6, 2), (14, 7, 3), (16, 8, 2), (16, 8, 8), (18, 9, 4), (17, 5, 5)])
+def test_shard_plan_is_consistent(pkg, L, nup, P, monkeypatch):
+    monkeypatch.setenv("SD_SUFFIX_BITS", "8")      # many tiles even at small L
+    models = []
+    for r in range(P):
+        m = pkg.XXZChain(L, nup=nup, ctx=None)
+        m.set_shard(r, P)
+        models.append(m)
+    infos = [m.shard_info() for m in models]
+    N = models[0].N
+    # owned ranges tile [0, N) in rank order
+    assert infos[0].row_lo == 0 and infos[-1].row_hi == N
+    for a, b in zip(infos[:-1], infos[1:]):
+        assert a.row_hi == b.row_lo
+    slabs = [m.shard_slabs() for m in models]
+    for r in range(P):
+        recv, send = slabs[r]
+        off = infos[r].n_local
+        for (peer, lo, cnt, g) in recv:             # halo slabs are packed back to back after the owned rows
+            assert lo == off and cnt > 0 and peer != r
+            assert infos[peer].row_lo <= g and g + cnt <= infos[peer].row_hi
+            off += cnt
+        assert off == infos[r].n_local + infos[r].n_halo
+        for (peer, lo, cnt, g) in send:
+            assert 0 <= lo and lo + cnt <= infos[r].n_local and g == infos[r].row_lo + lo
+        for q in range(P):                          # what r sends to q is exactly what q receives from r, in order
+            s = [(c, g) for (peer, _, c, g) in send if peer == q]
+            t = [(c, g) for (peer, _, c, g) in slabs[q][0] if peer == r]
+            assert s == t
+    # every hop partner of every owned row is either owned or inside a received slab
+    full = pkg.XXZChain(L, nup=nup, ctx=None)
+    st = full.states
+    for r in range(P):
+        lo, hi = infos[r].row_lo, infos[r].row_hi
+        have = np.zeros(N, dtype=bool)
+        have[lo:hi] = True
+        for (_, _, cnt, g) in slabs[r][0]:
+            have[g:g + cnt] = True
+        rows = st[lo:hi].astype(np.uint64)
+        for i in range(1, L):
+            bi = (rows >> np.uint64(i - 1)) & np.uint64(1)
+            bj = (rows >> np.uint64(i)) & np.uint64(1)
+            fl = rows[bi != bj] ^ np.uint64((1 << (i - 1)) | (1 << i))
+            assert have[full.rank(fl)].all()
