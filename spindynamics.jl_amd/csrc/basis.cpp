@@ -74,7 +74,7 @@ static void enum_sector(int n, int t, std::vector<uint16_t> &out) {
 }
 
 static int suffix_bits_from_env() {
-  int ls = 13;
+  int ls = 12;   // C(12,6) = 924-row tiles: 14.8 KB of LDS in ComplexF64, 5 workgroups of 256 threads per CU
   if (const char *e = getenv("SD_SUFFIX_BITS")) ls = atoi(e);
   if (ls < 2) ls = 2;
   if (ls > 15) ls = 15;

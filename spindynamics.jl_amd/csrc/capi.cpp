@@ -1,7 +1,9 @@
 // C ABI: contexts, models, operator-level entry points (include/spindyn.h).
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <new>
+#include <vector>
 
 #include "sd_internal.hpp"
 
@@ -317,6 +319,37 @@ int sd_bench_apply_dev(sd_ctx *ctx, const sd_model *m, int dtype, void *buf_a, v
   SD_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
   *ms_per_apply = ms / reps;
   return SD_OK;
+}
+
+// Diagnostic only (not in include/spindyn.h): runs one apply with per-tile s_memtime stamps and returns the mean
+// shader-cycle duration of each phase (prologue, list, diag+LDS, far bonds, barrier, suffix, epilogue) and the
+// mean tile lifetime.  Never used by the product path.
+int sd_debug_phase_profile(sd_ctx *ctx, sd_model *m, int dtype, void *out, const void *psi, double *phases /*8*/) {
+  if (!ctx || !m || !m->dev_ready || m->p < 0) return SD_EARG;
+  const size_t nt = m->tile_prefix.size();
+  unsigned long long *d = nullptr;
+  SD_HIP(ctx, hipMalloc((void **)&d, nt * 8 * sizeof(unsigned long long)));
+  SD_HIP(ctx, hipMemset(d, 0, nt * 8 * sizeof(unsigned long long)));
+  m->dm.stamps = d;
+  sd_epi_args ea;
+  int rc = sd_launch_apply(ctx, m, dtype, out, psi, SD_EPI_PLAIN, ea);
+  m->dm.stamps = nullptr;
+  if (!rc) {
+    std::vector<unsigned long long> h(nt * 8);
+    hipError_t e = hipMemcpy(h.data(), d, nt * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = SD_EHIP;
+    for (int k = 0; k < 8; ++k) phases[k] = 0.0;
+    unsigned long long tmin = ~0ull, tmax = 0;
+    for (size_t t = 0; t < nt; ++t) {
+      for (int k = 0; k < 6; ++k) phases[k] += (double)(h[8 * t + k + 1] - h[8 * t + k]);
+      phases[6] += (double)(h[8 * t + 6] - h[8 * t]);
+      tmin = std::min(tmin, h[8 * t + 7]); tmax = std::max(tmax, h[8 * t + 7]);
+    }
+    for (int k = 0; k < 7; ++k) phases[k] /= (double)nt;
+    phases[7] = (double)(tmax - tmin) * 10.0;  // ns between first and last tile end (100 MHz realtime counter)
+  }
+  (void)hipFree(d);
+  return rc;
 }
 
 int sd_fill_randn_dev(sd_ctx *ctx, void *x, int64_t n, uint64_t seed, uint64_t first) {

@@ -234,7 +234,7 @@ __device__ __forceinline__ double rld(double v, int lane) { return __longlong_as
 
 struct FarBond { int64_t base; double J; int lo, hi, shift; };
 
-template <int NC, int R, int BLOCK, bool FMA>
+template <int NC, int R, int BLOCK, bool FMA, bool DIAG = false>
 __global__ __launch_bounds__(BLOCK) void k_apply_tiled(sd_dev_model dm, double *__restrict__ out_,
                                                        const double *__restrict__ psi_, int epi, sd_epi_args ea,
                                                        double *__restrict__ partials, int max_len) {
@@ -256,6 +256,18 @@ __global__ __launch_bounds__(BLOCK) void k_apply_tiled(sd_dev_model dm, double *
   const int nU = (int)binom_g(dm, LS - 1, t2 - 1);  // rows whose first suffix site is up
   const uint16_t *__restrict__ sufS = dm.suf_states + dm.suf_off[t2];
   const int nn = dm.nn_hops;
+  unsigned long long *stamp = (DIAG && dm.stamps) ? dm.stamps + 8 * (size_t)tix : nullptr;
+#define SD_STAMP(k)                                                                   \
+  do {                                                                                \
+    if (DIAG && stamp) {                                                              \
+      __builtin_amdgcn_sched_barrier(0);                                              \
+      unsigned long long t__;                                                         \
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory"); \
+      __builtin_amdgcn_sched_barrier(0);                                              \
+      if (tid == 0) stamp[k] = t__;                                                   \
+    }                                                                                 \
+  } while (0)
+  SD_STAMP(0);
 
   // ---- 1. request own rows and suffix configurations ----
   V own[R];
@@ -313,12 +325,14 @@ __global__ __launch_bounds__(BLOCK) void k_apply_tiled(sd_dev_model dm, double *
     }
   };
 
+  SD_STAMP(1);
   // first far bond in flight before the own rows have even arrived
   V va[R], vb[R];
   FarBond fa{}, fbb{};
   uint64_t mk = fmask;
   bool have_a = false;
-  if (mk) { fa = get_bond(__builtin_ctzll(mk)); mk &= mk - 1; issue(fa, va); have_a = true; }
+  auto next_lane = [&](uint64_t &m_) { const int ln = __builtin_ctzll(m_); m_ &= m_ - 1; return ln; };   // ascending bond order
+  if (mk) { fa = get_bond(next_lane(mk)); issue(fa, va); have_a = true; }
 
   // ---- diagonal (needs own) ----
   V acc[R];
@@ -335,10 +349,11 @@ __global__ __launch_bounds__(BLOCK) void k_apply_tiled(sd_dev_model dm, double *
     lbin[k] = (int)binom_g(dm, n, kk);
   }
 
+  SD_STAMP(2);
   // ---- 3. far bonds: ping-pong pipeline, accumulation in bond order ----
   while (have_a) {
     bool have_b = false;
-    if (mk) { fbb = get_bond(__builtin_ctzll(mk)); mk &= mk - 1; issue(fbb, vb); have_b = true; }
+    if (mk) { fbb = get_bond(next_lane(mk)); issue(fbb, vb); have_b = true; }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int i = irow[r];
@@ -346,14 +361,16 @@ __global__ __launch_bounds__(BLOCK) void k_apply_tiled(sd_dev_model dm, double *
     }
     have_a = false;
     if (!have_b) break;
-    if (mk) { fa = get_bond(__builtin_ctzll(mk)); mk &= mk - 1; issue(fa, va); have_a = true; }
+    if (mk) { fa = get_bond(next_lane(mk)); issue(fa, va); have_a = true; }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int i = irow[r];
       if (i >= fbb.lo && i < fbb.hi) acc[r] = accum<FMA>(acc[r], fbb.J, vb[r]);
     }
   }
+  SD_STAMP(3);
   __syncthreads();
+  SD_STAMP(4);
 
   // ---- 4. bonds inside the suffix: LDS reads at idx +- C(LS-a-1, u) ----
   if (nn > 0 && !(dm.dbg & 4)) {
@@ -391,6 +408,7 @@ __global__ __launch_bounds__(BLOCK) void k_apply_tiled(sd_dev_model dm, double *
     }
   }
 
+  SD_STAMP(5);
   // ---- 5. epilogue + store ----
   EpiSums sums{0.0, 0.0};
 #pragma unroll
@@ -398,6 +416,8 @@ __global__ __launch_bounds__(BLOCK) void k_apply_tiled(sd_dev_model dm, double *
     const int i = tid + r * BLOCK;
     if (i < len) epilogue<NC>(epi, ea, base + i, acc[r], tile[i], out_, sums);
   }
+  SD_STAMP(6);
+  if (DIAG && stamp && tid == 0) stamp[7] = __builtin_amdgcn_s_memrealtime();
   if (epi_has_sums(epi)) {
     double a = sums.s0, b = sums.s1;
     block_reduce2(a, b, red);
@@ -508,7 +528,10 @@ int ensure_partials(sd_ctx *ctx, size_t doubles) {
 template <int NC, int R, int BLOCK, bool FMA>
 int launch_tiled_cfg(sd_ctx *ctx, const sd_dev_model &dm, int nt, size_t shmem, double *out, const double *psi, int epi,
                      const sd_epi_args &ea, int max_len) {
-  auto kern = k_apply_tiled<NC, R, BLOCK, FMA>;
+  // the stamped (DIAG) instantiation exists for one configuration only and is reached through sd_debug_phase_profile
+  void (*kern)(sd_dev_model, double *, const double *, int, sd_epi_args, double *, int) = k_apply_tiled<NC, R, BLOCK, FMA>;
+  if constexpr (NC == 2 && BLOCK == 256 && FMA)
+    if (dm.stamps) kern = k_apply_tiled<NC, R, BLOCK, FMA, true>;
   static size_t attr_set = 0;
   if (shmem > 48 * 1024 && shmem > attr_set) {
     SD_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
@@ -522,8 +545,8 @@ int launch_tiled_cfg(sd_ctx *ctx, const sd_dev_model &dm, int nt, size_t shmem, 
 template <int NC, bool FMA>
 int launch_tiled(sd_ctx *ctx, const sd_dev_model &dm, int nt, size_t shmem, double *out, const double *psi, int epi,
                  const sd_epi_args &ea, int max_len) {
-  // rows per thread: 4 for ComplexF64, 8 for Float64 (same register footprint); smallest block that covers a tile
-  constexpr int R = NC == 2 ? 4 : 8;
+  // 4 rows per thread; smallest block that covers the longest tile
+  constexpr int R = 4;
   if (max_len <= 256 * R) return launch_tiled_cfg<NC, R, 256, FMA>(ctx, dm, nt, shmem, out, psi, epi, ea, max_len);
   if (max_len <= 512 * R) return launch_tiled_cfg<NC, R, 512, FMA>(ctx, dm, nt, shmem, out, psi, epi, ea, max_len);
   if (max_len <= 1024 * R) return launch_tiled_cfg<NC, R, 1024, FMA>(ctx, dm, nt, shmem, out, psi, epi, ea, max_len);

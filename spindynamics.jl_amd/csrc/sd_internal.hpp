@@ -71,6 +71,7 @@ struct sd_dev_model {
   const uint16_t *suf_states;    // concatenated sectors (LS, t'), t' = 0..LS
   const int32_t *suf_off;        // LS+2 offsets into suf_states
   const uint16_t *suf_rank;      // 2^LS entries: rank of sigma inside its sector
+  unsigned long long *stamps;    // diagnostic builds only (sd_debug_phase_profile): 8 s_memtime stamps per tile, else null
 };
 
 struct sd_model {
