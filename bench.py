@@ -28,7 +28,10 @@ def cpu_baseline(L, nup, budget_s=20.0):
     import numpy as np
     from oracle import oracle as O
     from math import comb
-    Ls = int(os.environ.get("SD_BENCH_CPU_L", "24"))
+    Ls = int(os.environ.get("SD_BENCH_CPU_L", "26"))
+    # the GPU box gives one GPU a 16-core CPU share; more OpenMP threads than that only oversubscribe
+    ncores = int(os.environ.get("SD_BENCH_CPU_THREADS", str(min(16, os.cpu_count() or 1))))
+    O.set_num_threads(ncores)
     t0 = time.time()
     m = O.XXZChain(Ls, nup=Ls // 2)
     build_s = time.time() - t0

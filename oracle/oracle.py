@@ -302,3 +302,7 @@ def lanczos_sqw(model, psi0, q_list, omega, lanc_m=200, eta=0.05, broaden="loren
 
 def num_threads():
     return int(lib().so_num_threads())
+
+
+def set_num_threads(n):
+    lib().so_set_num_threads(C.c_int(int(n)))

@@ -899,6 +899,14 @@ int so_lanczos_sqw(const so_model *m, int nc, const double *psi0, const double *
   return rc;
 }
 
+void so_set_num_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
+
 int so_num_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

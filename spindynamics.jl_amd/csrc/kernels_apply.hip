@@ -232,16 +232,34 @@ __device__ __forceinline__ int64_t rl64(int64_t v, int lane) {
 }
 __device__ __forceinline__ double rld(double v, int lane) { return __longlong_as_double(rl64(__double_as_longlong(v), lane)); }
 
-struct FarBond { int64_t base; double J; int lo, hi, shift; };
+struct FarBond { int64_t base; double J; int lo, n; };   // partner rows: psi[base + (i - lo)] for lo <= i < lo + n
+
+// 128-bit buffer descriptor over [p, p + bytes): loads with a byte offset >= bytes return 0 (hardware range check),
+// which replaces every per-row "is this row in range" test of the far-bond streams.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ void buf_load(double &v, __amdgpu_buffer_rsrc_t r, uint32_t off) {
+  typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+  const u2 raw = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0);
+  v = __hiloint2double((int)raw.y, (int)raw.x);
+}
+__device__ __forceinline__ void buf_load(double2 &v, __amdgpu_buffer_rsrc_t r, uint32_t off) {
+  typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+  const u4 raw = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+  v.x = __hiloint2double((int)raw.y, (int)raw.x);
+  v.y = __hiloint2double((int)raw.w, (int)raw.z);
+}
 
 template <int NC, int R, int BLOCK, bool FMA, bool DIAG = false>
 __global__ __launch_bounds__(BLOCK) void k_apply_tiled(sd_dev_model dm, double *__restrict__ out_,
                                                        const double *__restrict__ psi_, int epi, sd_epi_args ea,
                                                        double *__restrict__ partials, int max_len) {
   using V = typename VT<NC>::type;
+  constexpr uint32_t ES = sizeof(V);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  V *tile = reinterpret_cast<V *>(smem);
-  int *lbin = reinterpret_cast<int *>(smem + (size_t)max_len * sizeof(V));
+  V *tile = reinterpret_cast<V *>(smem);                       // max_len rows + one all-zero row at index max_len
+  int *lbin = reinterpret_cast<int *>(smem + (size_t)(max_len + 1) * sizeof(V));
   double *red = reinterpret_cast<double *>(lbin + 16 * SD_BIN_STRIDE);
 
   const V *__restrict__ psi = reinterpret_cast<const V *>(psi_);
@@ -269,23 +287,28 @@ __global__ __launch_bounds__(BLOCK) void k_apply_tiled(sd_dev_model dm, double *
   } while (0)
   SD_STAMP(0);
 
-  // ---- 1. request own rows and suffix configurations ----
+  // ---- 1. request own rows (rows >= len read 0 through the range check) and suffix configurations ----
   V own[R];
   uint32_t sig[R];
-  int irow[R];
+  uint32_t ioff[R];   // byte offset of the row inside a tile-sized stream
+  int irow[R];        // row index clamped into the tile (LDS addressing of idle rows)
+  {
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(psi + base, (uint32_t)len * ES);
 #pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const int i = tid + r * BLOCK;
-    irow[r] = i < len ? i : len - 1;
-    own[r] = psi[base + irow[r]];
-    sig[r] = sufS[irow[r]];
+    for (int r = 0; r < R; ++r) {
+      const int i = tid + r * BLOCK;
+      ioff[r] = (uint32_t)i * ES;
+      irow[r] = i < len ? i : len - 1;
+      buf_load(own[r], rs, ioff[r]);
+      sig[r] = sufS[irow[r]];
+    }
   }
 
   // ---- 2. per-wave list of flippable far bonds (lane b-1 <-> bond b <= p-1, lane p-1 <-> straddle) ----
   uint64_t fmask = 0;
   int64_t my_base = 0;
   double my_J = 0.0;
-  int my_lo = 0, my_hi = len, my_shift = 0;
+  int my_lo = 0, my_n = len;
   if (nn > 0 && p >= 1) {
     bool fl = false;
     const int b = lane + 1;
@@ -293,17 +316,18 @@ __global__ __launch_bounds__(BLOCK) void k_apply_tiled(sd_dev_model dm, double *
       fl = (((P >> (b - 1)) ^ (P >> b)) & 1u) && !(dm.dbg & 1);
       if (fl) { my_base = dm.addr[P ^ (3u << (b - 1))]; my_J = dm.hop_J[b - 1]; }
     } else if (b == p) {
-      // bit p of P up: our rows with first suffix site down (i >= nU) <-> partner rows i - nU
-      // bit p of P down: our rows with first suffix site up (i < nU)  <-> partner rows nUq + i
+      // bit p of P up:   our rows with first suffix site down (i >= nU) <-> partner rows i - nU
+      // bit p of P down: our rows with first suffix site up   (i <  nU) <-> partner rows nUq + i
       const uint32_t bitp = (P >> (p - 1)) & 1u;
       const uint32_t Q = P ^ (1u << (p - 1));
       const int t2q = dm.nup - __popc(Q);
       if (t2q >= 0 && t2q <= LS && !(dm.dbg & 2)) {
         const int nUq = (int)binom_g(dm, LS - 1, t2q - 1);
-        if (bitp) { my_lo = nU; my_hi = len; my_shift = -nU; }
-        else { my_lo = 0; my_hi = nU; my_shift = nUq; }
-        fl = my_hi > my_lo;
-        if (fl) { my_base = dm.addr[Q]; my_J = dm.hop_J[p - 1]; }
+        int64_t shift;
+        if (bitp) { my_lo = nU; my_n = len - nU; shift = 0; }
+        else { my_lo = 0; my_n = nU; shift = nUq; }
+        fl = my_n > 0;
+        if (fl) { my_base = dm.addr[Q] + shift; my_J = dm.hop_J[p - 1]; }
       }
     }
     fmask = __ballot(fl);
@@ -312,17 +336,15 @@ __global__ __launch_bounds__(BLOCK) void k_apply_tiled(sd_dev_model dm, double *
   auto get_bond = [&](int ln) {
     FarBond fb;
     fb.base = rl64(my_base, ln); fb.J = rld(my_J, ln);
-    fb.lo = rl(my_lo, ln); fb.hi = rl(my_hi, ln); fb.shift = rl(my_shift, ln);
+    fb.lo = rl(my_lo, ln); fb.n = rl(my_n, ln);
     return fb;
   };
+  // rows outside [lo, lo+n) wrap to a huge unsigned offset or exceed n*ES: the load returns 0 and J*0 leaves acc unchanged
   auto issue = [&](const FarBond &fb, V(&v)[R]) {
-    const V *__restrict__ src = psi + fb.base;
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(psi + fb.base, (uint32_t)fb.n * ES);
+    const uint32_t lo_b = (uint32_t)fb.lo * ES;
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int i = irow[r];
-      const bool in = (i >= fb.lo) && (i < fb.hi);
-      v[r] = src[in ? i + fb.shift : 0];
-    }
+    for (int r = 0; r < R; ++r) buf_load(v[r], rs, ioff[r] - lo_b);
   };
 
   SD_STAMP(1);
@@ -344,6 +366,7 @@ __global__ __launch_bounds__(BLOCK) void k_apply_tiled(sd_dev_model dm, double *
 #pragma unroll
   for (int r = 0; r < R; ++r)
     if (tid + r * BLOCK < len) tile[irow[r]] = own[r];
+  if (tid == 0) tile[max_len] = V{};   // the zero row read by lanes whose suffix bond is not flippable
   for (int k = tid; k < 16 * SD_BIN_STRIDE; k += BLOCK) {
     int n = k / SD_BIN_STRIDE, kk = k - n * SD_BIN_STRIDE;
     lbin[k] = (int)binom_g(dm, n, kk);
@@ -355,39 +378,38 @@ __global__ __launch_bounds__(BLOCK) void k_apply_tiled(sd_dev_model dm, double *
     bool have_b = false;
     if (mk) { fbb = get_bond(next_lane(mk)); issue(fbb, vb); have_b = true; }
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int i = irow[r];
-      if (i >= fa.lo && i < fa.hi) acc[r] = accum<FMA>(acc[r], fa.J, va[r]);
-    }
+    for (int r = 0; r < R; ++r) acc[r] = accum<FMA>(acc[r], fa.J, va[r]);
     have_a = false;
     if (!have_b) break;
     if (mk) { fa = get_bond(next_lane(mk)); issue(fa, va); have_a = true; }
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int i = irow[r];
-      if (i >= fbb.lo && i < fbb.hi) acc[r] = accum<FMA>(acc[r], fbb.J, vb[r]);
-    }
+    for (int r = 0; r < R; ++r) acc[r] = accum<FMA>(acc[r], fbb.J, vb[r]);
   }
   SD_STAMP(3);
   __syncthreads();
   SD_STAMP(4);
 
-  // ---- 4. bonds inside the suffix: LDS reads at idx +- C(LS-a-1, u) ----
+  // ---- 4. bonds inside the suffix: LDS reads at idx +- C(LS-a-1, u); branch-free so the R rows' reads overlap ----
   if (nn > 0 && !(dm.dbg & 4)) {
+    uint32_t dw[R];   // bit a-1 set <=> suffix bond a is flippable
+#pragma unroll
+    for (int r = 0; r < R; ++r) dw[r] = sig[r] ^ (sig[r] >> 1);
     for (int a = 1; a <= LS - 1; ++a) {
       const double J = dm.hop_J[p + a - 1];
       const int *brow = lbin + (LS - a - 1) * SD_BIN_STRIDE;
+      int d[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) d[r] = brow[__popc(sig[r] >> (a + 1))];
+      V v[R];
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        const uint32_t sg = sig[r];
-        const uint32_t ba = (sg >> (a - 1)) & 1u, bb = (sg >> a) & 1u;
-        if (ba != bb) {
-          const int u = __popc(sg >> (a + 1));
-          const int d = brow[u];
-          const int ip = ba ? irow[r] + d : irow[r] - d;
-          acc[r] = accum<FMA>(acc[r], J, tile[ip]);
-        }
+        const bool up = (sig[r] >> (a - 1)) & 1u;
+        const bool fl = (dw[r] >> (a - 1)) & 1u;
+        const int ip = up ? irow[r] + d[r] : irow[r] - d[r];
+        v[r] = tile[fl ? ip : max_len];
       }
+#pragma unroll
+      for (int r = 0; r < R; ++r) acc[r] = accum<FMA>(acc[r], J, v[r]);
     }
   }
   // ---- remaining (general) bonds: rank through the tile tables ----
@@ -567,7 +589,7 @@ int sd_launch_apply(sd_ctx *ctx, const sd_model *m, int dtype, void *out, const 
     if (sums) { int rc = ensure_partials(ctx, 2 * (size_t)nt); if (rc) return rc; }
     const int max_len = m->max_tile_len;
     const size_t esz = dtype == SD_C128 ? 16 : 8;
-    const size_t shmem = (size_t)max_len * esz + 16 * SD_BIN_STRIDE * sizeof(int) + 32 * sizeof(double) + 16;
+    const size_t shmem = (size_t)(max_len + 1) * esz + 16 * SD_BIN_STRIDE * sizeof(int) + 32 * sizeof(double) + 16;
     int rc;
     if (dtype == SD_C128)
       rc = m->hop_pow2 ? launch_tiled<2, true>(ctx, dm, nt, shmem, (double *)out, (const double *)psi, epi, ea, max_len)
