@@ -226,6 +226,36 @@ int sd_build_plan(sd_model *m, int rank, int nranks, std::string &err) {
     }
   }
 
+  // Grouping (single-GPU NN-chain plans).  Candidate generators are the odd prefix bonds (1,2),(3,4),... : they are
+  // pairwise disjoint, so flipping one never changes whether another is flippable.  A tile whose first three flippable
+  // candidates are b1<b2<b3 belongs, with its 7 images under those flips, to one group: the 8 tiles are staged in one
+  // LDS image and the three (far, never L2-resident) bonds are served from LDS.  Tiles with fewer than three flippable
+  // candidates stay single.  Pure speed-up: the accumulation order per row is unchanged.
+  m->group_P0.clear(); m->group_gens.clear();
+  m->single_prefix = m->tile_prefix; m->single_base = m->tile_base;
+  {
+    int gb = 0;
+    if (const char *e = getenv("SD_GROUP_BONDS")) gb = atoi(e);
+    m->group_ngen = 0;
+    const bool pure_nn = count_nn_hops(m) > 0 && (int)m->hop_i.size() == count_nn_hops(m);
+    if ((gb == 2 || gb == 3) && nranks == 1 && pure_nn && p >= 2 * gb + 1 &&
+        ((size_t)m->max_tile_len << gb) * 16 <= 140 * 1024) {
+      m->group_ngen = gb;
+      std::vector<uint32_t> sp; std::vector<int64_t> sb;
+      for (size_t k = 0; k < m->tile_prefix.size(); ++k) {
+        const uint32_t P = m->tile_prefix[k];
+        int g[3] = {0, 0, 0}, ng = 0;
+        for (int b = 1; b + 1 <= p && ng < gb; b += 2)
+          if (((P >> (b - 1)) ^ (P >> b)) & 1u) g[ng++] = b;
+        if (ng < gb) { sp.push_back(P); sb.push_back(m->tile_base[k]); continue; }
+        bool canonical = true;
+        for (int i = 0; i < gb; ++i) if (!((P >> (g[i] - 1)) & 1u)) canonical = false;   // pair must be (up, down)
+        if (canonical) { m->group_P0.push_back(P); m->group_gens.push_back((uint32_t)g[0] | ((uint32_t)g[1] << 8) | ((uint32_t)g[2] << 16)); }
+      }
+      m->single_prefix.swap(sp); m->single_base.swap(sb);
+    }
+  }
+
   if (nranks > 1) {
     const int nn = count_nn_hops(m);
     std::vector<uint8_t> need(nP);
@@ -350,6 +380,12 @@ int sd_upload_model(sd_model *m, std::string &err) {
     if ((rc = up(m, m->suf_states, &d.suf_states, err))) return rc;
     if ((rc = up(m, m->suf_off, &d.suf_off, err))) return rc;
     if ((rc = up(m, m->suf_rank, &d.suf_rank, err))) return rc;
+    d.n_groups = (int)m->group_P0.size();
+    d.n_singles = (int)m->single_prefix.size();
+    if ((rc = up(m, m->single_prefix, &d.single_prefix, err))) return rc;
+    if ((rc = up(m, m->single_base, &d.single_base, err))) return rc;
+    if ((rc = up(m, m->group_P0, &d.group_P0, err))) return rc;
+    if ((rc = up(m, m->group_gens, &d.group_gens, err))) return rc;
   }
   m->dev_ready = true;
   return SD_OK;

@@ -326,7 +326,8 @@ int sd_bench_apply_dev(sd_ctx *ctx, const sd_model *m, int dtype, void *buf_a, v
 // mean tile lifetime.  Never used by the product path.
 int sd_debug_phase_profile(sd_ctx *ctx, sd_model *m, int dtype, void *out, const void *psi, double *phases /*8*/) {
   if (!ctx || !m || !m->dev_ready || m->p < 0) return SD_EARG;
-  const size_t nt = m->tile_prefix.size();
+  if (!m->group_P0.empty()) return SD_EARG;   // profile with SD_GROUP_BONDS=0: stamps exist in the single-tile kernel only
+  const size_t nt = m->single_prefix.size();
   unsigned long long *d = nullptr;
   SD_HIP(ctx, hipMalloc((void **)&d, nt * 8 * sizeof(unsigned long long)));
   SD_HIP(ctx, hipMemset(d, 0, nt * 8 * sizeof(unsigned long long)));

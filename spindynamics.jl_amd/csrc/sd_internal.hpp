@@ -71,6 +71,12 @@ struct sd_dev_model {
   const uint16_t *suf_states;    // concatenated sectors (LS, t'), t' = 0..LS
   const int32_t *suf_off;        // LS+2 offsets into suf_states
   const uint16_t *suf_rank;      // 2^LS entries: rank of sigma inside its sector
+  // grouped path: 8 tiles related by three disjoint flippable top bonds share one workgroup / one LDS image
+  int n_groups, n_singles;
+  const uint32_t *single_prefix; // tiles not in any group (all tiles when grouping is off), processed by k_apply_tiled
+  const int64_t *single_base;
+  const uint32_t *group_P0;      // canonical member prefix (each generator pair in state up,down)
+  const uint32_t *group_gens;    // three generator bonds (1-based), 8 bits each
   unsigned long long *stamps;    // diagnostic builds only (sd_debug_phase_profile): 8 s_memtime stamps per tile, else null
 };
 
@@ -91,6 +97,10 @@ struct sd_model {
   std::vector<uint16_t> suf_states, suf_rank;
   std::vector<int32_t> suf_off;
   std::vector<sd_slab> recv_slabs, send_slabs;
+  std::vector<uint32_t> group_P0, group_gens;  // grouped tiles (unsharded NN-chain plans only)
+  std::vector<uint32_t> single_prefix;
+  int group_ngen = 0;          // generator bonds per group (2 or 3)
+  std::vector<int64_t> single_base;
   int max_tile_len = 0;
   bool hop_pow2 = false;  // every NN hop amplitude is +-2^k (or 0): J*psi is exact, fma == mul+add
   // device copies

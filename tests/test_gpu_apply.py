@@ -105,3 +105,21 @@ def test_dimension_and_argument_errors(pkg):
         pkg.XXZChain(64, nup=1)
     with pytest.raises(pkg.ArgumentError):
         pkg.XXZChain(6, nup=3, boundary="twisted")
+
+
+@pytest.mark.parametrize("gb", ["2", "3"])
+def test_grouped_kernel_opt_in_bit_exact(pkg, O, gb, monkeypatch):
+    """SD_GROUP_BONDS (experimental, default off): 4/8 tiles related by disjoint flippable top bonds share one
+    workgroup and one LDS image.  Same per-row accumulation order -> still bit-identical to the oracle."""
+    monkeypatch.setenv("SD_GROUP_BONDS", gb)
+    monkeypatch.setenv("SD_SUFFIX_BITS", "8")
+    for (L, nup) in [(18, 9), (20, 8), (19, 10)]:
+        m = pkg.XXZChain(L, nup=nup, Jz=0.7)
+        r = O.XXZChain(L, nup=nup, Jz=0.7)
+        psi = rand_vec(m.N, 77 + L)
+        out = np.empty_like(psi)
+        pkg.apply_H(out, psi, m)
+        assert np.array_equal(out, O.apply_H(r, psi))
+        a, b = 5.5, 0.25
+        pkg.apply_rescaled_H(out, psi, pkg.apply_H, m, a, b)
+        assert np.array_equal(out, O.apply_rescaled_H(r, psi, a, b))
