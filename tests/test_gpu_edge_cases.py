@@ -1,0 +1,84 @@
+"""Edge cases of the boundary on the GPU: tiny and degenerate sectors, very long chains with few up spins (generic
+combinadic path, 64-bit states), aliasing / null / dtype errors, torch device tensors."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("L,nup", [(1, 0), (1, 1), (1, None), (2, 0), (2, 2), (2, None), (3, 1), (40, 2), (63, 1), (50, 3), (33, 0)])
+def test_small_and_long_chains_bit_exact(pkg, O, L, nup):
+    m = pkg.XXZChain(L, Jxy=0.9, Jz=1.1, hz=0.3, nup=nup)
+    r = O.XXZChain(L, Jxy=0.9, Jz=1.1, hz=0.3, nup=nup)
+    assert m.N == r.N and np.array_equal(m.states, r.states)
+    rng = np.random.default_rng(L)
+    for cplx in (True, False):
+        psi = rng.standard_normal(m.N) + (1j * rng.standard_normal(m.N) if cplx else 0)
+        out = np.empty_like(psi)
+        pkg.apply_H(out, psi, m)
+        assert np.array_equal(out, O.apply_H(r, psi))
+    phi = pkg.Sz_q_vector(m, psi, 0.7)
+    assert np.abs(phi - O.Sz_q_vector(r, psi, 0.7)).max() <= 1e-15 * max(1.0, np.abs(phi).max())
+
+
+def test_device_paths_reported(pkg):
+    assert pkg.XXZChain(12, nup=6).device_path == "tiled"
+    assert pkg.XXZChain(8, nup=None).device_path == "generic"
+    assert pkg.XXZChain(50, nup=3).device_path == "generic"     # 2^38 prefix tiles would not fit a table
+
+
+def test_boundary_errors(pkg):
+    m = pkg.XXZChain(8, nup=4)
+    psi = np.zeros(m.N)
+    with pytest.raises(pkg.ArgumentError):
+        pkg.apply_H(psi, psi, m)                               # out must not alias psi
+    with pytest.raises(pkg.ArgumentError):
+        pkg.apply_H(np.zeros(m.N, np.float32), np.zeros(m.N, np.float32), m)
+    with pytest.raises(pkg.ArgumentError):
+        pkg.apply_H(np.zeros(m.N), np.zeros(m.N, complex), m)  # mixed element types
+    with pytest.raises(pkg.DimensionMismatch):
+        pkg.apply_H(np.zeros(m.N + 1), np.zeros(m.N + 1), m)
+    with pytest.raises(pkg.DimensionMismatch):
+        pkg.Sz_q_vector(m, np.zeros(m.N - 1), 0.1)
+    with pytest.raises(pkg.ArgumentError):
+        pkg.compute_chebyshev_moments(pkg.apply_H, np.ones(m.N, complex), 1, 1.0, 0.0, m)   # kpm_m >= 2
+    with pytest.raises(pkg.ArgumentError):
+        pkg.lanczos_extremal(lambda *a: None, m)               # the device recursions need the device operator
+
+
+def test_torch_device_tensors_and_streams(pkg, O):
+    import torch
+    m = pkg.XXZChain(14, nup=7)
+    r = O.XXZChain(14, nup=7)
+    psi = np.random.default_rng(1).standard_normal(m.N)
+    want = O.apply_H(r, psi)
+    d = torch.from_numpy(psi).cuda()
+    out = torch.empty_like(d)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):                                 # the launch follows torch's current stream
+        pkg.apply_H(out, d, m)
+    s.synchronize()
+    assert np.array_equal(out.cpu().numpy(), want)
+    phi = pkg.Sz_q_vector(m, d, 1.1)
+    assert phi.is_cuda and np.abs(phi.cpu().numpy() - O.Sz_q_vector(r, psi, 1.1)).max() <= 1e-15
+
+
+def test_kpm_sum_rule_medium_size(pkg):
+    """Size-independent property (test/test_KPM.jl:67-91 at L=20): integral of S(q,w) over the whole band equals
+    |S^z_q psi0|^2 for ANY psi0 when (a,b) cover the spectrum; Jackson kernel, M=160: 1 % (kernel resolution)."""
+    L = 20
+    m = pkg.XXZChain(L, nup=L // 2)
+    rng = np.random.default_rng(5)
+    psi0 = rng.standard_normal(m.N)
+    psi0 /= np.linalg.norm(psi0)
+    lo, hi = pkg.estimate_energy_bounds(pkg.apply_H, m, lanc_m=60, seed=1)
+    a, b = pkg.rescaling_from_bounds(lo, hi)
+    Hpsi = np.empty_like(psi0)
+    pkg.apply_H(Hpsi, psi0, m)
+    E0 = float(psi0 @ Hpsi)
+    omega = np.arange(lo - E0 - 0.5, hi - E0 + 0.5, 0.01)
+    q = np.array([np.pi / 2, np.pi])
+    S = pkg.kpm_sqw(psi0, m, q, omega, a=a, b=b, kpm_m=160)
+    for iq in range(2):
+        w = np.linalg.norm(pkg.Sz_q_vector(m, psi0, float(q[iq]))) ** 2
+        assert abs(S[iq].sum() * 0.01 - w) <= 1e-2 * w
