@@ -458,7 +458,7 @@ __global__ __launch_bounds__(BLOCK) void k_apply_tiled(sd_dev_model dm, double *
 // single staging barrier the teams run independently (far-bond streams, suffix bonds, store), which overlaps one
 // team's memory phase with another's LDS/VALU phase.  Per-row accumulation order is unchanged (bit-identical results).
 template <int NC, bool FMA, int NGEN>
-__global__ __launch_bounds__(128 << NGEN) void k_apply_grouped(sd_dev_model dm, double *__restrict__ out_,
+__global__ __launch_bounds__(128 << NGEN, 4) void k_apply_grouped(sd_dev_model dm, double *__restrict__ out_,
                                                         const double *__restrict__ psi_, int epi, sd_epi_args ea,
                                                         double *__restrict__ partials, int max_len) {
   using V = typename VT<NC>::type;

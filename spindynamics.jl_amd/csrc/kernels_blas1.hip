@@ -42,7 +42,13 @@ __global__ __launch_bounds__(BS) void k_dot(const double *__restrict__ x, const 
       b += u.x * v.y - u.y * v.x;
     }
   } else {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += stride) a += x[i] * y[i];
+    const int64_t n2 = (((uintptr_t)x | (uintptr_t)y) & 15) ? 0 : N / 2;
+    const double2 *x2 = (const double2 *)x, *y2 = (const double2 *)y;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
+      double2 u = x2[i], v = y2[i];
+      a += u.x * v.x + u.y * v.y;
+    }
+    for (int64_t i = 2 * n2 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += stride) a += x[i] * y[i];
   }
   block_reduce2(a, b, red);
   if (threadIdx.x == 0) { partials[2 * blockIdx.x] = a; partials[2 * blockIdx.x + 1] = b; }
@@ -52,7 +58,10 @@ __global__ __launch_bounds__(BS) void k_nrm2sq(const double *__restrict__ x, int
   __shared__ double red[32];
   double a = 0.0, b = 0.0;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) { double v = x[i]; a += v * v; }
+  const int64_t n2 = ((uintptr_t)x & 15) ? 0 : n / 2;
+  const double2 *x2 = (const double2 *)x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) { double2 v = x2[i]; a += v.x * v.x + v.y * v.y; }
+  for (int64_t i = 2 * n2 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) { double v = x[i]; a += v * v; }
   block_reduce2(a, b, red);
   if (threadIdx.x == 0) { partials[2 * blockIdx.x] = a; partials[2 * blockIdx.x + 1] = b; }
 }
@@ -68,17 +77,74 @@ __global__ __launch_bounds__(1024) void k_reduce_to(const double *__restrict__ p
 enum { OP_SCALE_DIV, OP_NEG, OP_SUB_AXPBY, OP_SUB_AXPBY1, OP_SUB2, OP_SUB2_1 };
 
 template <int OP>
+__device__ __forceinline__ double ew_op(double w, double v, double u, double a, double b) {
+  if (OP == OP_SCALE_DIV) return v / a;
+  if (OP == OP_NEG) return -w;
+  if (OP == OP_SUB_AXPBY) return w - (a * v + b * u);
+  if (OP == OP_SUB_AXPBY1) return w - a * v;
+  if (OP == OP_SUB2) return (w - a * v) - b * u;
+  return w - a * v;  // OP_SUB2_1
+}
+template <int OP> struct ew_reads { static constexpr bool w = OP != OP_SCALE_DIV, v = OP != OP_NEG, u = OP == OP_SUB_AXPBY || OP == OP_SUB2; };
+
+// elementwise pass with 16-byte accesses (n2 = number of double2 elements); NORM accumulates |w_new|^2
+template <int OP, bool NORM>
+__global__ __launch_bounds__(BS) void k_ew2(double2 *__restrict__ w, const double2 *__restrict__ v,
+                                            const double2 *__restrict__ u, int64_t n2, double a, double b,
+                                            double *__restrict__ partials) {
+  __shared__ double red[32];
+  double s = 0.0, s1 = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
+    const double2 z = make_double2(0.0, 0.0);
+    const double2 ww = ew_reads<OP>::w ? w[i] : z, vv = ew_reads<OP>::v ? v[i] : z, uu = ew_reads<OP>::u ? u[i] : z;
+    const double2 r = make_double2(ew_op<OP>(ww.x, vv.x, uu.x, a, b), ew_op<OP>(ww.y, vv.y, uu.y, a, b));
+    w[i] = r;
+    if (NORM) s += r.x * r.x + r.y * r.y;
+  }
+  if (NORM) {
+    block_reduce2(s, s1, red);
+    if (threadIdx.x == 0) { partials[2 * blockIdx.x] = s; partials[2 * blockIdx.x + 1] = 0.0; }
+  }
+}
+
+// scalar fallback (odd length or 8-byte aligned columns)
+template <int OP, bool NORM>
 __global__ __launch_bounds__(BS) void k_ew(double *__restrict__ w, const double *__restrict__ v,
-                                           const double *__restrict__ u, int64_t n, double a, double b) {
+                                           const double *__restrict__ u, int64_t n, double a, double b,
+                                           double *__restrict__ partials) {
+  __shared__ double red[32];
+  double s = 0.0, s1 = 0.0;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    if (OP == OP_SCALE_DIV) w[i] = v[i] / a;
-    else if (OP == OP_NEG) w[i] = -w[i];
-    else if (OP == OP_SUB_AXPBY) w[i] = w[i] - (a * v[i] + b * u[i]);
-    else if (OP == OP_SUB_AXPBY1) w[i] = w[i] - a * v[i];
-    else if (OP == OP_SUB2) w[i] = (w[i] - a * v[i]) - b * u[i];
-    else if (OP == OP_SUB2_1) w[i] = w[i] - a * v[i];
+    const double r = ew_op<OP>(ew_reads<OP>::w ? w[i] : 0.0, ew_reads<OP>::v ? v[i] : 0.0, ew_reads<OP>::u ? u[i] : 0.0, a, b);
+    w[i] = r;
+    if (NORM) s += r * r;
   }
+  if (NORM) {
+    block_reduce2(s, s1, red);
+    if (threadIdx.x == 0) { partials[2 * blockIdx.x] = s; partials[2 * blockIdx.x + 1] = 0.0; }
+  }
+}
+
+// w = (w - alpha*v) - b*u  with complex alpha (src/TimeEvolution/Krylov.jl:156-159), fused |w|^2
+__global__ __launch_bounds__(BS) void k_krylov_update(double2 *__restrict__ w, const double2 *__restrict__ v,
+                                                      const double2 *__restrict__ u, int64_t N, double ar, double ai,
+                                                      double b, int have_u, double *__restrict__ partials) {
+  __shared__ double red[32];
+  double s = 0.0, s1 = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += stride) {
+    const double2 x = v[i];
+    double2 y = w[i];
+    y.x -= ar * x.x - ai * x.y;
+    y.y -= ar * x.y + ai * x.x;
+    if (have_u) { const double2 z = u[i]; y.x -= b * z.x; y.y -= b * z.y; }
+    w[i] = y;
+    s += y.x * y.x + y.y * y.y;
+  }
+  block_reduce2(s, s1, red);
+  if (threadIdx.x == 0) { partials[2 * blockIdx.x] = s; partials[2 * blockIdx.x + 1] = 0.0; }
 }
 
 // w -= alpha*v (complex alpha) ; y += alpha*x
@@ -191,25 +257,53 @@ int sd_read_scalars(sd_ctx *ctx, int slot, int count, double *out) {
   return SD_OK;
 }
 
+namespace {
+// one elementwise pass; when slot >= 0 the pass also reduces |w_new|^2 into ctx->d_scalars[slot]
+template <int OP>
+int launch_ew(sd_ctx *ctx, double *w, const double *v, const double *u, int64_t n, double a, double b, int slot) {
+  const bool vec = (n % 2 == 0) && !((((uintptr_t)w) | ((uintptr_t)v) | ((uintptr_t)u)) & 15);
+  const int64_t items = vec ? n / 2 : n;
+  unsigned nb = grid_for(items);
+  if (slot >= 0) {
+    if (nb > RED_BLOCKS) nb = RED_BLOCKS;
+    int rc = ensure_partials(ctx, 2 * RED_BLOCKS); if (rc) return rc;
+    if (vec) hipLaunchKernelGGL((k_ew2<OP, true>), dim3(nb), dim3(BS), 0, ctx->stream, (double2 *)w, (const double2 *)v, (const double2 *)u, items, a, b, ctx->d_partials);
+    else hipLaunchKernelGGL((k_ew<OP, true>), dim3(nb), dim3(BS), 0, ctx->stream, w, v, u, items, a, b, ctx->d_partials);
+    hipLaunchKernelGGL(k_reduce_to, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_partials, (int)nb, ctx->d_scalars + slot);
+  } else {
+    if (vec) hipLaunchKernelGGL((k_ew2<OP, false>), dim3(nb), dim3(BS), 0, ctx->stream, (double2 *)w, (const double2 *)v, (const double2 *)u, items, a, b, (double *)nullptr);
+    else hipLaunchKernelGGL((k_ew<OP, false>), dim3(nb), dim3(BS), 0, ctx->stream, w, v, u, items, a, b, (double *)nullptr);
+  }
+  SD_HIP(ctx, hipGetLastError());
+  return SD_OK;
+}
+}  // namespace
+
 int sd_k_scale_div(sd_ctx *ctx, double *y, const double *x, int64_t n, double d) {
-  hipLaunchKernelGGL(k_ew<OP_SCALE_DIV>, dim3(grid_for(n)), dim3(BS), 0, ctx->stream, y, x, (const double *)nullptr, n, d, 0.0);
-  SD_HIP(ctx, hipGetLastError());
-  return SD_OK;
+  return launch_ew<OP_SCALE_DIV>(ctx, y, x, nullptr, n, d, 0.0, -1);
 }
-int sd_k_neg(sd_ctx *ctx, double *x, int64_t n) {
-  hipLaunchKernelGGL(k_ew<OP_NEG>, dim3(grid_for(n)), dim3(BS), 0, ctx->stream, x, (const double *)nullptr, (const double *)nullptr, n, 0.0, 0.0);
-  SD_HIP(ctx, hipGetLastError());
-  return SD_OK;
-}
+int sd_k_neg(sd_ctx *ctx, double *x, int64_t n) { return launch_ew<OP_NEG>(ctx, x, nullptr, nullptr, n, 0.0, 0.0, -1); }
 int sd_k_sub_axpby(sd_ctx *ctx, double *w, const double *v, const double *u, int64_t n, double a, double b) {
-  if (u) hipLaunchKernelGGL(k_ew<OP_SUB_AXPBY>, dim3(grid_for(n)), dim3(BS), 0, ctx->stream, w, v, u, n, a, b);
-  else hipLaunchKernelGGL(k_ew<OP_SUB_AXPBY1>, dim3(grid_for(n)), dim3(BS), 0, ctx->stream, w, v, u, n, a, b);
-  SD_HIP(ctx, hipGetLastError());
-  return SD_OK;
+  return u ? launch_ew<OP_SUB_AXPBY>(ctx, w, v, u, n, a, b, -1) : launch_ew<OP_SUB_AXPBY1>(ctx, w, v, nullptr, n, a, b, -1);
 }
 int sd_k_sub2(sd_ctx *ctx, double *w, const double *v, const double *u, int64_t n, double a, double b) {
-  if (u) hipLaunchKernelGGL(k_ew<OP_SUB2>, dim3(grid_for(n)), dim3(BS), 0, ctx->stream, w, v, u, n, a, b);
-  else hipLaunchKernelGGL(k_ew<OP_SUB2_1>, dim3(grid_for(n)), dim3(BS), 0, ctx->stream, w, v, u, n, a, b);
+  return u ? launch_ew<OP_SUB2>(ctx, w, v, u, n, a, b, -1) : launch_ew<OP_SUB2_1>(ctx, w, v, nullptr, n, a, b, -1);
+}
+// fused forms: same update + |w|^2 -> d_scalars[slot]
+int sd_k_sub_axpby_nrm(sd_ctx *ctx, double *w, const double *v, const double *u, int64_t n, double a, double b, int slot) {
+  return u ? launch_ew<OP_SUB_AXPBY>(ctx, w, v, u, n, a, b, slot) : launch_ew<OP_SUB_AXPBY1>(ctx, w, v, nullptr, n, a, b, slot);
+}
+int sd_k_sub2_nrm(sd_ctx *ctx, double *w, const double *v, const double *u, int64_t n, double a, double b, int slot) {
+  return u ? launch_ew<OP_SUB2>(ctx, w, v, u, n, a, b, slot) : launch_ew<OP_SUB2_1>(ctx, w, v, nullptr, n, a, b, slot);
+}
+int sd_k_krylov_update_nrm(sd_ctx *ctx, double *w, const double *v, const double *u, int64_t N, double ar, double ai,
+                           double b, int slot) {
+  int rc = ensure_partials(ctx, 2 * RED_BLOCKS); if (rc) return rc;
+  unsigned nb = grid_for(N);
+  if (nb > RED_BLOCKS) nb = RED_BLOCKS;
+  hipLaunchKernelGGL(k_krylov_update, dim3(nb), dim3(BS), 0, ctx->stream, (double2 *)w, (const double2 *)v, (const double2 *)u, N,
+                     ar, ai, b, u ? 1 : 0, ctx->d_partials);
+  hipLaunchKernelGGL(k_reduce_to, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_partials, (int)nb, ctx->d_scalars + slot);
   SD_HIP(ctx, hipGetLastError());
   return SD_OK;
 }

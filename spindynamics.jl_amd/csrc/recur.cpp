@@ -85,9 +85,9 @@ int extremal_dev(sd_ctx *ctx, const sd_model *m, int lanc_m, double tol, double 
     RC(sd_launch_apply(ctx, m, SD_C128, w.p, v_prev, SD_EPI_DOT, ea));     // :51 + :55 fused
     double s[2]; RC(sd_read_scalars(ctx, 0, 2, s));
     alpha[j - 1] = s[0];
-    RC(sd_k_sub_axpby(ctx, w.p, v_prev, j == 1 ? nullptr : v_curr, 2 * N, alpha[j - 1], j == 1 ? 0.0 : beta[j - 2]));
+    RC(sd_k_sub_axpby_nrm(ctx, w.p, v_prev, j == 1 ? nullptr : v_curr, 2 * N, alpha[j - 1], j == 1 ? 0.0 : beta[j - 2], 2));
     if (j < mm) {
-      beta[j - 1] = norm_dev(ctx, w.p, 2 * N, &rc); RC(rc);               // :65
+      { double q; RC(sd_read_scalars(ctx, 2, 1, &q)); beta[j - 1] = std::sqrt(q); }   // :65 (norm fused into the update pass)
       if (beta[j - 1] < tol) { actual = j; break; }                       // :66-70
       std::swap(v_curr, v_prev);
       RC(sd_k_scale_div(ctx, v_prev, w.p, 2 * N, beta[j - 1]));           // :71
@@ -142,14 +142,14 @@ int tridiag_dev(sd_ctx *ctx, const sd_model *m, double *vcur /* normalised start
   double *w = wb.p, *vprev = vp.p;
   for (int k = 0; k < mm; ++k) alpha[k] = 0.0;
   for (int k = 0; k + 1 < mm; ++k) beta[k] = 0.0;
-  int m_eff = mm, rc = 0;
+  int m_eff = mm;
   sd_epi_args ea;
   for (int j = 1; j <= mm - 1; ++j) {
     RC(sd_launch_apply(ctx, m, SD_C128, w, vcur, SD_EPI_DOT, ea));                                 // :218-219
     double s[2]; RC(sd_read_scalars(ctx, 0, 2, s));
     alpha[j - 1] = s[0];
-    RC(sd_k_sub2(ctx, w, vcur, j > 1 ? vprev : nullptr, 2 * n, alpha[j - 1], j > 1 ? beta[j - 2] : 0.0));  // :222-224
-    beta[j - 1] = norm_dev(ctx, w, 2 * n, &rc); RC(rc);                                           // :227
+    RC(sd_k_sub2_nrm(ctx, w, vcur, j > 1 ? vprev : nullptr, 2 * n, alpha[j - 1], j > 1 ? beta[j - 2] : 0.0, 2));  // :222-224
+    { double q; RC(sd_read_scalars(ctx, 2, 1, &q)); beta[j - 1] = std::sqrt(q); }                   // :227 (fused)
     if (beta[j - 1] < tol) { m_eff = j; break; }
     std::swap(vprev, vcur);
     RC(sd_k_scale_div(ctx, vcur, w, 2 * n, beta[j - 1]));                                         // :233
@@ -446,10 +446,10 @@ extern "C" int sd_krylov_evolve(sd_ctx *ctx, const sd_model *m, int dtype, const
     RC(sd_launch_apply(ctx, m, SD_C128, w.p, V[j - 1].p, SD_EPI_DOT, ea));                // :153,155
     double s[2]; RC(sd_read_scalars(ctx, 0, 2, s));
     alr[j - 1] = s[0];
-    RC(sd_k_csub(ctx, w.p, V[j - 1].p, n, s[0], s[1]));                                   // :156
-    if (j > 1) RC(sd_k_sub2(ctx, w.p, V[j - 2].p, nullptr, 2 * n, beta[j - 2], 0.0));      // :157-159
+    RC(sd_k_krylov_update_nrm(ctx, w.p, V[j - 1].p, j > 1 ? V[j - 2].p : nullptr, n, s[0], s[1],
+                              j > 1 ? beta[j - 2] : 0.0, 2));                              // :156-159 + :161 in one pass
     if (j < kry_m) {
-      beta[j - 1] = norm_dev(ctx, w.p, 2 * n, &rc); RC(rc);                               // :161
+      { double q; RC(sd_read_scalars(ctx, 2, 1, &q)); beta[j - 1] = std::sqrt(q); }
       if (std::fabs(beta[j - 1]) < 1e-14) { m_eff = j; break; }                           // :162-168
       RC(V[j].alloc(ctx, 2 * n));
       RC(sd_k_scale_div(ctx, V[j].p, w.p, 2 * n, beta[j - 1]));                           // :169

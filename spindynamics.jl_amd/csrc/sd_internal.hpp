@@ -153,6 +153,10 @@ int sd_k_neg(sd_ctx *ctx, double *x, int64_t n);
 int sd_k_sub_axpby(sd_ctx *ctx, double *w, const double *v, const double *u, int64_t n, double a, double b);
 // w = (w - a*v) - b*u   (two roundings: src/Lanczos.jl:222-224, :127-129); u may be null
 int sd_k_sub2(sd_ctx *ctx, double *w, const double *v, const double *u, int64_t n, double a, double b);
+// fused update + squared norm into d_scalars[slot] (one pass instead of update, norm)
+int sd_k_sub_axpby_nrm(sd_ctx *ctx, double *w, const double *v, const double *u, int64_t n, double a, double b, int slot);
+int sd_k_sub2_nrm(sd_ctx *ctx, double *w, const double *v, const double *u, int64_t n, double a, double b, int slot);
+int sd_k_krylov_update_nrm(sd_ctx *ctx, double *w, const double *v, const double *u, int64_t N, double ar, double ai, double b, int slot);
 // w -= (ar + i ai) * v  for complex vectors (src/TimeEvolution/Krylov.jl:156)
 int sd_k_csub(sd_ctx *ctx, double *w, const double *v, int64_t N, double ar, double ai);
 // y += (ar + i ai) * x  complex accumulate (Krylov reconstruction :186-188)
