@@ -181,6 +181,25 @@ int sd_lanczos_sqw(sd_ctx *ctx, const sd_model *m, int dtype, const void *psi0_h
                    const double *q, int Qn, const double *omega, int W, int lanc_m, double eta, int broaden,
                    double *Smat_out);
 
+/* ---- observables and initial states (reference src/Observables.jl, src/InitialStates.jl) ---- */
+/* magnetization_per_site   src/Observables.jl:14-36 : mags_out[L] = <S^z_i> */
+int sd_magnetization(sd_ctx *ctx, const sd_model *m, int dtype, const void *psi_host, int64_t n, double *mags_out);
+int sd_magnetization_dev(sd_ctx *ctx, const sd_model *m, int dtype, const void *psi_dev, int64_t n, double *mags_out);
+/* connected_correlations   src/Observables.jl:44-94 : C_out[L], C_r = (1/L) sum_i (<S_i S_j> - <S_i><S_j>), j = mod1(i+r,L) */
+int sd_connected_correlations(sd_ctx *ctx, const sd_model *m, int dtype, const void *psi_host, int64_t n, double *C_out);
+int sd_connected_correlations_dev(sd_ctx *ctx, const sd_model *m, int dtype, const void *psi_dev, int64_t n, double *C_out);
+/* structure_factor_Sq   src/Observables.jl:100-109 : q_out[k] = 2 pi k / L, S_out[k] = real(fft(C_r))[k] */
+int sd_structure_factor(sd_ctx *ctx, const sd_model *m, int dtype, const void *psi_host, int64_t n, double *q_out, double *S_out);
+int sd_structure_factor_dev(sd_ctx *ctx, const sd_model *m, int dtype, const void *psi_dev, int64_t n, double *q_out, double *S_out);
+/* InitialStates (src/InitialStates.jl:9-130): 0-based basis index of the one-hot state; SD_EARG when the
+ * configuration is not in the basis.  flips: 1-based sites for SD_STATE_POLARIZED_FLIPS. */
+#define SD_STATE_DOMAIN_WALL 0
+#define SD_STATE_NEEL 1
+#define SD_STATE_POLARIZED_UP 2
+#define SD_STATE_POLARIZED_DOWN 3
+#define SD_STATE_POLARIZED_FLIPS 4
+int sd_initial_state_index(const sd_model *m, int kind, const int *flips, int nflips, int64_t *idx0_out);
+
 /* ---- host utilities ------------------------------------------------------ */
 /* eigen(SymTridiagonal(d, e)): ascending eigenvalues w[n]; z (n*n column-major) may be NULL */
 int sd_symtridiag_eig(int n, const double *d, const double *e, double *w, double *z);

@@ -300,6 +300,50 @@ def lanczos_sqw(model, psi0, q_list, omega, lanc_m=200, eta=0.05, broaden="loren
     return S
 
 
+def magnetization_per_site(psi, model):
+    psi, nc = _vec(psi)
+    out = np.empty(model.L)
+    _chk(lib().so_magnetization_per_site(model._h, C.c_int(nc), _dp(psi.view(np.float64)), C.c_int64(psi.shape[0]), _dp(out)))
+    return out
+
+
+def connected_correlations(psi, model):
+    psi, nc = _vec(psi)
+    out = np.empty(model.L)
+    _chk(lib().so_connected_correlations(model._h, C.c_int(nc), _dp(psi.view(np.float64)), C.c_int64(psi.shape[0]), _dp(out)))
+    return out
+
+
+def structure_factor_Sq(psi, model):
+    psi, nc = _vec(psi)
+    q, S = np.empty(model.L), np.empty(model.L)
+    _chk(lib().so_structure_factor_Sq(model._h, C.c_int(nc), _dp(psi.view(np.float64)), C.c_int64(psi.shape[0]), _dp(q), _dp(S)))
+    return {float(a): float(b) for a, b in zip(q, S)}
+
+
+def _initial(model, kind, flips=()):
+    f = np.array(list(flips), dtype=np.int32)
+    out = np.empty(model.N)
+    _chk(lib().so_initial_state(model._h, C.c_int(kind), f.ctypes.data_as(_i32p), C.c_int(len(f)), _dp(out)))
+    return out
+
+
+def domain_wall_state(model):
+    return _initial(model, 0)
+
+
+def neel_state(model):
+    return _initial(model, 1)
+
+
+def polarized_state(model, up=True):
+    return _initial(model, 2 if up else 3)
+
+
+def polarized_state_with_flips(model, flips):
+    return _initial(model, 4, flips)
+
+
 def num_threads():
     return int(lib().so_num_threads())
 

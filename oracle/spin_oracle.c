@@ -899,6 +899,100 @@ int so_lanczos_sqw(const so_model *m, int nc, const double *psi0, const double *
   return rc;
 }
 
+
+/* ------------------------------------------------------------------ */
+/* Observables ("next" row f2) and InitialStates (f3)                  */
+/* ------------------------------------------------------------------ */
+
+/* src/Observables.jl:14-36 magnetization_per_site: mags[i] = sum_idx |psi|^2 s_i */
+int so_magnetization_per_site(const so_model *m, int nc, const double *psi, int64_t N, double *mags) {
+  const int L = m->L, full = (m->nup < 0);
+  if (!full && N != m->N) return SO_EDIM;
+  for (int i = 0; i < L; ++i) mags[i] = 0.0;
+  for (int64_t idx = 0; idx < N; ++idx) {
+    double re = psi[idx * nc], im = nc == 2 ? psi[idx * nc + 1] : 0.0;
+    double prob = re * re + im * im;
+    if (prob != 0.0) {
+      uint64_t state = full ? (uint64_t)idx : m->states[idx];
+      for (int i = 0; i < L; ++i) mags[i] += prob * sz_value(bit_at(state, i));
+    }
+  }
+  return SO_OK;
+}
+
+/* src/Observables.jl:44-94 connected_correlations: C_r = (1/L) sum_i (<S_i S_j> - <S_i><S_j>), j = mod1(i+r, L)
+ * (periodic wrap even for open chains, :86) */
+int so_connected_correlations(const so_model *m, int nc, const double *psi, int64_t N, double *C_r) {
+  const int L = m->L, full = (m->nup < 0);
+  if (!full && N != m->N) return SO_EDIM;
+  double *SzSz = (double *)calloc((size_t)L * L, sizeof(double));
+  double *S_i = (double *)calloc(L, sizeof(double));
+  for (int64_t idx = 0; idx < N; ++idx) {
+    double re = psi[idx * nc], im = nc == 2 ? psi[idx * nc + 1] : 0.0;
+    double amp2 = re * re + im * im;
+    if (amp2 == 0.0) continue;
+    uint64_t state = full ? (uint64_t)idx : m->states[idx];
+    for (int i = 0; i < L; ++i) {
+      double szi = sz_value(bit_at(state, i));
+      S_i[i] += amp2 * szi;
+      for (int j = 0; j < L; ++j) SzSz[i + (size_t)L * j] += amp2 * szi * sz_value(bit_at(state, j));
+    }
+  }
+  for (int r = 0; r < L; ++r) {
+    double tmp = 0.0;
+    for (int i = 1; i <= L; ++i) {
+      int j = ((i + r - 1) % L) + 1;                /* mod1(i+r, L) */
+      tmp += SzSz[(i - 1) + (size_t)L * (j - 1)] - S_i[i - 1] * S_i[j - 1];
+    }
+    C_r[r] = tmp / L;
+  }
+  free(SzSz); free(S_i);
+  return SO_OK;
+}
+
+/* src/Observables.jl:100-109 structure_factor_Sq: real(fft(C_r))[n], q_n = 2 pi (n-1)/L  (plain DFT, L is tiny) */
+int so_structure_factor_Sq(const so_model *m, int nc, const double *psi, int64_t N, double *q, double *Sq) {
+  const double PI = 3.14159265358979323846;
+  const int L = m->L;
+  double C[64];
+  int rc = so_connected_correlations(m, nc, psi, N, C);
+  if (rc) return rc;
+  for (int n = 0; n < L; ++n) {
+    double s = 0.0;
+    for (int r = 0; r < L; ++r) s += C[r] * cos(2 * PI * n * r / L);
+    q[n] = 2 * PI * n / L;
+    Sq[n] = s;
+  }
+  return SO_OK;
+}
+
+/* src/InitialStates.jl:9-130: one-hot Float64 vectors.  kind: 0 domain wall (:9-34), 1 Neel (:40-63),
+ * 2 polarized up, 3 polarized down (:70-89), 4 polarized with flips (:97-130; flips are 1-based sites).
+ * Returns SO_EARG when the configuration is not in the basis (ArgumentError in the reference). */
+int so_initial_state(const so_model *m, int kind, const int *flips, int nflips, double *psi0) {
+  const int L = m->L;
+  uint64_t s = 0;
+  if (kind == 0) {
+    int nup = m->nup >= 0 ? m->nup : (L + 1) / 2;        /* Int(ceil(L/2)) */
+    for (int i = 0; i < nup; ++i) s |= (uint64_t)1 << i;
+  } else if (kind == 1) {
+    for (int i = 0; i < L; ++i) if (((i + 1) & 1) == 1) s |= (uint64_t)1 << i;
+  } else if (kind == 2) {
+    s = ((uint64_t)1 << L) - 1;
+  } else if (kind == 3) {
+    s = 0;
+  } else if (kind == 4) {
+    for (int k = 0; k < nflips; ++k) if (flips[k] < 1 || flips[k] > L) return SO_EARG;
+    s = ((uint64_t)1 << L) - 1;
+    for (int k = 0; k < nflips; ++k) s ^= (uint64_t)1 << (flips[k] - 1);
+  } else return SO_EARG;
+  int64_t idx = so_lookup(m, s);
+  if (idx == 0) return SO_EARG;
+  for (int64_t i = 0; i < m->N; ++i) psi0[i] = 0.0;
+  psi0[idx - 1] = 1.0;
+  return SO_OK;
+}
+
 void so_set_num_threads(int n) {
 #ifdef _OPENMP
   if (n > 0) omp_set_num_threads(n);

@@ -14,7 +14,10 @@ from .solvers import (chebyshev_coeffs, chebyshev_time_evolve, compute_chebyshev
                       get_kernel, get_rescaling_params, kpm_reconstruct, kpm_sqw, kpm_sw, krylov_time_evolve,
                       lanczos_extremal, lanczos_groundstate, lanczos_sqw, lanczos_tridiag, rescaling_from_bounds,
                       spectral_from_tridiagonal, symtridiag_eig)
-from .api import dynamical_structure_factor, groundstate, time_evolve
+from .observables import connected_correlations, magnetization_per_site, structure_factor_Sq
+from . import initial_states
+from .initial_states import domain_wall_state, neel_state, polarized_state, polarized_state_with_flips
+from .api import dynamical_structure_factor, groundstate, structure_factor, time_evolve
 from .dist import ShardedOperator
 
 __all__ = [n for n in dir() if not n.startswith("_")]

@@ -88,6 +88,13 @@ PROTOTYPES = {
     "sd_kpm_sqw": (_i, [_vp, _vp, _i, _vp, _i64, _dp, _i, _dp, _i, _i, _d, _d, _i, _i, _u64, _dp]),
     "sd_spectral_from_tridiagonal": (_i, [_dp, _dp, _i, _d, _d, _dp, _i, _d, _i, _dp]),
     "sd_lanczos_sqw": (_i, [_vp, _vp, _i, _vp, _i64, _dp, _i, _dp, _i, _i, _d, _i, _dp]),
+    "sd_magnetization": (_i, [_vp, _vp, _i, _vp, _i64, _dp]),
+    "sd_magnetization_dev": (_i, [_vp, _vp, _i, _vp, _i64, _dp]),
+    "sd_connected_correlations": (_i, [_vp, _vp, _i, _vp, _i64, _dp]),
+    "sd_connected_correlations_dev": (_i, [_vp, _vp, _i, _vp, _i64, _dp]),
+    "sd_structure_factor": (_i, [_vp, _vp, _i, _vp, _i64, _dp, _dp]),
+    "sd_structure_factor_dev": (_i, [_vp, _vp, _i, _vp, _i64, _dp, _dp]),
+    "sd_initial_state_index": (_i, [_vp, _i, _ip, _i, _i64p]),
     "sd_symtridiag_eig": (_i, [_i, _dp, _dp, _dp, _dp]),
     "sd_chebyshev_coeffs": (_i, [_i, _d, _d, _d, _dp]),
     "sd_fill_randn_dev": (_i, [_vp, _vp, _i64, _u64, _u64]),

@@ -26,6 +26,12 @@ def time_evolve(model, psi0, t, method="krylov", Ebounds=None, **kwargs):
     raise ArgumentError(f"unsupported time-evolution method: {method}")
 
 
+def structure_factor(model, psi):
+    """structure_factor(model, psi) -> same mapping as structure_factor_Sq -- src/PublicAPI.jl:101-106"""
+    from .observables import structure_factor_Sq
+    return structure_factor_Sq(psi, model)
+
+
 def dynamical_structure_factor(model, psi0, q, omega, method="lanczos", **kwargs):
     """dynamical_structure_factor(model, psi0, q, omega; method=:lanczos, kwargs...) -> S[len(q), len(omega)]
     -- src/PublicAPI.jl:122-155"""

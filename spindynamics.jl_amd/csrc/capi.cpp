@@ -353,6 +353,91 @@ int sd_debug_phase_profile(sd_ctx *ctx, sd_model *m, int dtype, void *out, const
   return rc;
 }
 
+// ---- observables / initial states ("next" rows f2, f3) ----
+
+static int obs_dev(sd_ctx *ctx, const sd_model *m, int dtype, const void *psi, int64_t n, int what, double *out, double *q_out) {
+  if (!ctx) return SD_EARG;
+  if (!m || !psi || !out) return sd_set_err(ctx, SD_EARG, "null argument");
+  if (m->nranks != 1) return sd_set_err(ctx, SD_EARG, "observables need an unsharded model");
+  if (n != m->N) return sd_set_err(ctx, SD_EDIM, "vector length does not match the basis dimension");
+  const int L = m->L;
+  if (what == 0) return sd_launch_observable(ctx, m, dtype, psi, 0, out);       // magnetization_per_site
+  std::vector<double> S(L), R(L), Cr(L);
+  int rc = sd_launch_observable(ctx, m, dtype, psi, 0, S.data());
+  if (!rc) rc = sd_launch_observable(ctx, m, dtype, psi, 1, R.data());
+  if (rc) return rc;
+  for (int r = 0; r < L; ++r) {                                                   // src/Observables.jl:83-91
+    double prod = 0.0;
+    for (int i = 1; i <= L; ++i) { const int j = ((i + r - 1) % L) + 1; prod += S[i - 1] * S[j - 1]; }
+    Cr[r] = (R[r] - prod) / L;
+  }
+  if (what == 1) { for (int r = 0; r < L; ++r) out[r] = Cr[r]; return SD_OK; }
+  const double PI = 3.14159265358979323846;                                      // :100-109, plain DFT of C_r
+  for (int k = 0; k < L; ++k) {
+    double s = 0.0;
+    for (int r = 0; r < L; ++r) s += Cr[r] * std::cos(2 * PI * k * r / L);
+    out[k] = s;
+    if (q_out) q_out[k] = 2 * PI * k / L;
+  }
+  return SD_OK;
+}
+
+static int obs_host(sd_ctx *ctx, const sd_model *m, int dtype, const void *psi, int64_t n, int what, double *out, double *q_out) {
+  if (!ctx) return SD_EARG;
+  if (!m || !psi || !out) return sd_set_err(ctx, SD_EARG, "null argument");
+  if (dtype != SD_F64 && dtype != SD_C128) return sd_set_err(ctx, SD_EARG, "bad dtype");
+  if (n != m->N) return sd_set_err(ctx, SD_EDIM, "vector length does not match the basis dimension");
+  const size_t bytes = (size_t)n * (dtype == SD_C128 ? 16 : 8);
+  TmpDev d(ctx);
+  int rc = d.alloc(bytes);
+  if (rc) return rc;
+  SD_HIP(ctx, hipMemcpyAsync(d.p, psi, bytes, hipMemcpyHostToDevice, ctx->stream));
+  return obs_dev(ctx, m, dtype, d.p, n, what, out, q_out);
+}
+
+int sd_magnetization(sd_ctx *ctx, const sd_model *m, int dtype, const void *psi_host, int64_t n, double *mags_out) {
+  return obs_host(ctx, m, dtype, psi_host, n, 0, mags_out, nullptr);
+}
+int sd_magnetization_dev(sd_ctx *ctx, const sd_model *m, int dtype, const void *psi_dev, int64_t n, double *mags_out) {
+  return obs_dev(ctx, m, dtype, psi_dev, n, 0, mags_out, nullptr);
+}
+int sd_connected_correlations(sd_ctx *ctx, const sd_model *m, int dtype, const void *psi_host, int64_t n, double *C_out) {
+  return obs_host(ctx, m, dtype, psi_host, n, 1, C_out, nullptr);
+}
+int sd_connected_correlations_dev(sd_ctx *ctx, const sd_model *m, int dtype, const void *psi_dev, int64_t n, double *C_out) {
+  return obs_dev(ctx, m, dtype, psi_dev, n, 1, C_out, nullptr);
+}
+int sd_structure_factor(sd_ctx *ctx, const sd_model *m, int dtype, const void *psi_host, int64_t n, double *q_out, double *S_out) {
+  return obs_host(ctx, m, dtype, psi_host, n, 2, S_out, q_out);
+}
+int sd_structure_factor_dev(sd_ctx *ctx, const sd_model *m, int dtype, const void *psi_dev, int64_t n, double *q_out, double *S_out) {
+  return obs_dev(ctx, m, dtype, psi_dev, n, 2, S_out, q_out);
+}
+
+int sd_initial_state_index(const sd_model *m, int kind, const int *flips, int nflips, int64_t *idx0_out) {
+  if (!m || !idx0_out || nflips < 0 || (nflips && !flips)) return SD_EARG;
+  const int L = m->L;
+  uint64_t s = 0;
+  if (kind == SD_STATE_DOMAIN_WALL) {                          // src/InitialStates.jl:9-34
+    const int nup = m->nup >= 0 ? m->nup : (L + 1) / 2;
+    for (int i = 0; i < nup; ++i) s |= (uint64_t)1 << i;
+  } else if (kind == SD_STATE_NEEL) {                          // :40-63
+    for (int i = 0; i < L; i += 2) s |= (uint64_t)1 << i;
+  } else if (kind == SD_STATE_POLARIZED_UP) {                  // :70-89
+    s = ((uint64_t)1 << L) - 1;
+  } else if (kind == SD_STATE_POLARIZED_DOWN) {
+    s = 0;
+  } else if (kind == SD_STATE_POLARIZED_FLIPS) {               // :97-130
+    for (int k = 0; k < nflips; ++k) if (flips[k] < 1 || flips[k] > L) return fail(m->ctx, SD_EARG, "flip site is outside the model");
+    s = ((uint64_t)1 << L) - 1;
+    for (int k = 0; k < nflips; ++k) s ^= (uint64_t)1 << (flips[k] - 1);
+  } else return fail(m->ctx, SD_EARG, "unknown initial-state kind");
+  const int64_t idx = sd_rank_host(m, s);
+  if (idx < 0) return fail(m->ctx, SD_EARG, "requested state is not contained in the model basis");
+  *idx0_out = idx;
+  return SD_OK;
+}
+
 int sd_fill_randn_dev(sd_ctx *ctx, void *x, int64_t n, uint64_t seed, uint64_t first) {
   if (!ctx) return SD_EARG;
   if (!x || n < 0) return sd_set_err(ctx, SD_EARG, "bad argument");

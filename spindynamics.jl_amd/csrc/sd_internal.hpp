@@ -139,6 +139,7 @@ struct sd_epi_args {
 // partial sums, the reduced values land in ctx->d_scalars[0..1] (device).
 int sd_launch_apply(sd_ctx *ctx, const sd_model *m, int dtype, void *out, const void *psi, int epi,
                     const sd_epi_args &ea);
+int sd_launch_observable(sd_ctx *ctx, const sd_model *m, int dtype, const void *psi, int mode, double *out_host);
 int sd_launch_szq(sd_ctx *ctx, const sd_model *m, int dtype_in, const void *psi0, double q, void *phi);
 
 // BLAS-1 style kernels on device vectors of `n` doubles (n = nc * N).
