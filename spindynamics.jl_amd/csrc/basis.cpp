@@ -204,13 +204,56 @@ int sd_build_plan(sd_model *m, int rank, int nranks, std::string &err) {
   }
 
   // XCD-aware processing order.  Workgroups are dealt round-robin over the 8 XCDs (block b -> XCD b % 8), each with
-  // a private 4 MiB L2.  Give every XCD runs of CH consecutive tiles so that the near prefix bonds (partner tile a few
-  // tiles away) hit in that XCD's L2.  Affects speed only: the mapping is a bijection of the local tile list.
+  // a private 4 MiB L2.  A far bond maps tile P onto tile P' = P ^ bond and both read each other.  Tiles related by
+  // DISJOINT flippable top bonds (the odd prefix bonds (1,2),(3,4),..: flipping one never changes another) form orbits
+  // of 2^f tiles; the members of an orbit are queued back to back on ONE XCD, so that a member's partner reads for
+  // those bonds -- the first far bonds it processes, right after its own rows were fetched by the partner -- hit
+  // that XCD's L2 (or merge with the in-flight fetch) instead of going to the fabric again.  SD_XCD_ORBIT = max f
+  // (0 disables, then SD_XCD_CHUNK consecutive tiles per XCD are used).  Speed only: a bijection of the tile list.
   {
+    int FO = 6;
+    if (const char *e = getenv("SD_XCD_ORBIT")) FO = atoi(e);
+    if (FO > 8) FO = 8;
     int CH = 32;
     if (const char *e = getenv("SD_XCD_CHUNK")) CH = atoi(e);
     const size_t nt = m->tile_prefix.size();
-    if (CH > 0 && nt >= (size_t)16 * CH) {
+    if (FO > 0 && nt >= 64 && p >= 3 && count_nn_hops(m) > 0) {
+      // canonical orbit representative: chosen pairs set to (up, down); member id = which pairs are flipped
+      std::vector<uint64_t> key(nt);     // (first-seen rank of the orbit) << 8 | member id
+      std::vector<int64_t> first_seen((size_t)1 << p, -1);
+      int64_t n_orb = 0;
+      for (size_t k = 0; k < nt; ++k) {
+        const uint32_t P = m->tile_prefix[k];
+        uint32_t C0 = P; int member = 0, ng = 0;
+        for (int b = 1; b + 1 <= p && ng < FO; b += 2)
+          if (((P >> (b - 1)) ^ (P >> b)) & 1u) {
+            if (!((P >> (b - 1)) & 1u)) { C0 ^= 3u << (b - 1); member |= 1 << ng; }
+            ++ng;
+          }
+        if (first_seen[C0] < 0) first_seen[C0] = n_orb++;
+        key[k] = ((uint64_t)first_seen[C0] << 8) | (uint64_t)member;
+      }
+      std::vector<size_t> idx(nt);
+      for (size_t k = 0; k < nt; ++k) idx[k] = k;
+      std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return key[a] < key[b]; });
+      // deal whole orbits to the 8 XCD queues, then interleave the queues (position j of queue x -> block 8j + x)
+      std::vector<std::vector<size_t>> q(8);
+      size_t o = 0;
+      for (size_t k = 0; k < nt;) {
+        size_t e = k;
+        while (e < nt && (key[idx[e]] >> 8) == (key[idx[k]] >> 8)) ++e;
+        for (size_t t = k; t < e; ++t) q[o % 8].push_back(idx[t]);
+        ++o; k = e;
+      }
+      std::vector<uint32_t> tp; std::vector<int64_t> tb;
+      tp.reserve(nt); tb.reserve(nt);
+      size_t longest = 0;
+      for (auto &v : q) longest = std::max(longest, v.size());
+      for (size_t j = 0; j < longest; ++j)
+        for (int x = 0; x < 8; ++x)
+          if (j < q[x].size()) { tp.push_back(m->tile_prefix[q[x][j]]); tb.push_back(m->tile_base[q[x][j]]); }
+      m->tile_prefix.swap(tp); m->tile_base.swap(tb);
+    } else if (CH > 0 && nt >= (size_t)16 * CH) {
       std::vector<uint32_t> tp(nt);
       std::vector<int64_t> tb(nt);
       const size_t group = (size_t)8 * CH, full = nt / group * group;
@@ -382,6 +425,16 @@ int sd_upload_model(sd_model *m, std::string &err) {
     if ((rc = up(m, m->suf_rank, &d.suf_rank, err))) return rc;
     d.n_groups = (int)m->group_P0.size();
     d.n_singles = (int)m->single_prefix.size();
+    m->single_rec.resize(m->single_prefix.size());
+    for (size_t k = 0; k < m->single_prefix.size(); ++k) {
+      const uint32_t P = m->single_prefix[k];
+      const int t2 = m->nup - __builtin_popcount(P);
+      sd_tile_rec &r = m->single_rec[k];
+      r.base = m->single_base[k]; r.prefix = P;
+      r.len = (int32_t)B(m, m->LS, t2); r.nU = (int32_t)B(m, m->LS - 1, t2 - 1); r.suf_off = m->suf_off[t2];
+      r.pad0 = r.pad1 = 0;
+    }
+    if ((rc = up(m, m->single_rec, &d.single_rec, err))) return rc;
     if ((rc = up(m, m->single_prefix, &d.single_prefix, err))) return rc;
     if ((rc = up(m, m->single_base, &d.single_base, err))) return rc;
     if ((rc = up(m, m->group_P0, &d.group_P0, err))) return rc;

@@ -268,13 +268,13 @@ __global__ __launch_bounds__(BLOCK) void k_apply_tiled(sd_dev_model dm, double *
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int tix = blockIdx.x;
-  const uint32_t P = dm.single_prefix[tix];
-  const int64_t base = dm.single_base[tix];
+  const sd_tile_rec rec = dm.single_rec[tix];       // one 32-byte scalar load: no dependent table look-ups at start-up
+  const uint32_t P = rec.prefix;
+  const int64_t base = rec.base;
   const int p = dm.p, LS = dm.LS;
-  const int t2 = dm.nup - __popc(P);
-  const int len = (int)binom_g(dm, LS, t2);
-  const int nU = (int)binom_g(dm, LS - 1, t2 - 1);  // rows whose first suffix site is up
-  const uint16_t *__restrict__ sufS = dm.suf_states + dm.suf_off[t2];
+  const int len = rec.len;
+  const int nU = rec.nU;                            // rows whose first suffix site is up
+  const uint16_t *__restrict__ sufS = dm.suf_states + rec.suf_off;
   const int nn = dm.nn_hops;
   unsigned long long *stamp = (DIAG && dm.stamps) ? dm.stamps + 8 * (size_t)tix : nullptr;
 #define SD_STAMP(k)                                                                   \

@@ -30,6 +30,16 @@
 #define SD_MAX_BONDS 4096  // bond lists are uploaded to device memory; this bounds host validation only
 #define SD_MAX_PREFIX_BITS 26
 
+// everything a workgroup needs to start on a tile, fetched with one scalar load
+struct sd_tile_rec {
+  int64_t base;      // offset of the tile's first row in the local vector
+  uint32_t prefix;   // prefix configuration P
+  int32_t len;       // rows = C(LS, t'), t' = nup - popcount(P)
+  int32_t nU;        // rows whose first suffix site is up = C(LS-1, t'-1)
+  int32_t suf_off;   // offset of sector (LS, t') in suf_states
+  int32_t pad0, pad1;
+};
+
 struct sd_ctx {
   int device = 0;
   hipStream_t own_stream = nullptr;
@@ -75,6 +85,7 @@ struct sd_dev_model {
   int n_groups, n_singles;
   const uint32_t *single_prefix; // tiles not in any group (all tiles when grouping is off), processed by k_apply_tiled
   const int64_t *single_base;
+  const sd_tile_rec *single_rec;
   const uint32_t *group_P0;      // canonical member prefix (each generator pair in state up,down)
   const uint32_t *group_gens;    // three generator bonds (1-based), 8 bits each
   unsigned long long *stamps;    // diagnostic builds only (sd_debug_phase_profile): 8 s_memtime stamps per tile, else null
@@ -101,6 +112,7 @@ struct sd_model {
   std::vector<uint32_t> single_prefix;
   int group_ngen = 0;          // generator bonds per group (2 or 3)
   std::vector<int64_t> single_base;
+  std::vector<sd_tile_rec> single_rec;
   int max_tile_len = 0;
   bool hop_pow2 = false;  // every NN hop amplitude is +-2^k (or 0): J*psi is exact, fma == mul+add
   // device copies
