@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "sd_internal.hpp"
 
@@ -254,7 +255,7 @@ __device__ __forceinline__ void buf_load(double2 &v, __amdgpu_buffer_rsrc_t r, u
 }
 
 template <int NC, int R, int BLOCK, bool FMA, bool DIAG = false>
-__global__ __launch_bounds__(BLOCK) void k_apply_tiled(sd_dev_model dm, double *__restrict__ out_,
+__global__ __launch_bounds__(BLOCK, 4) void k_apply_tiled(sd_dev_model dm, double *__restrict__ out_,
                                                        const double *__restrict__ psi_, int epi, sd_epi_args ea,
                                                        double *__restrict__ partials, int max_len) {
   using V = typename VT<NC>::type;
