@@ -94,7 +94,7 @@ def main():
     b = op.empty(tdtype, dev)
     op.fill_randn(a, SEED)
     nrm = op.norm(a)
-    a[: op.n_local] /= nrm
+    a /= nrm
     b.zero_()
 
     def sync():

@@ -231,6 +231,13 @@ typedef struct sd_slab {
 /* Re-plans the model as shard `rank` of `nranks` (nranks == 1 restores the
  * unsharded plan).  Must be called before any apply on that model. */
 int sd_model_set_shard(sd_model *m, int rank, int nranks);
+/* Sharded apply with the imported partner tiles in a SEPARATE halo buffer (n_halo elements, filled by the exchange):
+ * vectors then hold exactly n_local elements and one halo buffer serves every vector of a recursion.
+ * epilogue: 0 out = H psi; 1 out = (H psi - b psi)/a; 2 fused Chebyshev term (ComplexF64; phi_prev, psi_t as in
+ * sd_cheb_step_dev).  All pointers are device pointers. */
+int sd_apply_sharded_dev(sd_ctx *ctx, const sd_model *m, int dtype, void *out_dev, const void *psi_dev,
+                         const void *halo_dev, int64_t n_local, int epilogue, double a, double b,
+                         double c_re, double c_im, const void *phi_prev_dev, void *psi_t_dev);
 int sd_model_shard_info(const sd_model *m, sd_shard_info *out);
 int sd_model_shard_slabs(const sd_model *m, sd_slab *recv_out, sd_slab *send_out);
 

@@ -100,6 +100,7 @@ PROTOTYPES = {
     "sd_fill_randn_dev": (_i, [_vp, _vp, _i64, _u64, _u64]),
     "sd_fill_randn_host": (_i, [_dp, _i64, _u64, _u64]),
     "sd_model_set_shard": (_i, [_vp, _i, _i]),
+    "sd_apply_sharded_dev": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i64, _i, _d, _d, _d, _d, _vp, _vp]),
     "sd_model_shard_info": (_i, [_vp, C.POINTER(sd_shard_info)]),
     "sd_model_shard_slabs": (_i, [_vp, C.POINTER(sd_slab), C.POINTER(sd_slab)]),
 }

@@ -229,6 +229,26 @@ int sd_apply_dev(sd_ctx *ctx, const sd_model *m, int dtype, void *out, const voi
   return sd_launch_apply(ctx, m, dtype, out, psi, SD_EPI_PLAIN, ea);
 }
 
+int sd_apply_sharded_dev(sd_ctx *ctx, const sd_model *m, int dtype, void *out, const void *psi, const void *halo,
+                         int64_t n_local, int epilogue, double a, double b, double c_re, double c_im,
+                         const void *phi_prev, void *psi_t) {
+  int rc = check_apply_args(ctx, m, dtype, out, psi, n_local);
+  if (rc) return rc;
+  if (n_local != m->n_local) return sd_set_err(ctx, SD_EDIM, "vector length does not match the local basis dimension");
+  if (m->n_halo > 0 && !halo) return sd_set_err(ctx, SD_EARG, "this shard needs a halo buffer");
+  sd_epi_args ea; ea.a = a; ea.b = b; ea.c_re = c_re; ea.c_im = c_im; ea.prev = phi_prev; ea.accv = psi_t; ea.halo = halo;
+  int epi;
+  switch (epilogue) {
+    case 0: epi = SD_EPI_PLAIN; break;
+    case 1: epi = SD_EPI_RESCALE; break;
+    case 2:
+      if (dtype != SD_C128 || !phi_prev || !psi_t) return sd_set_err(ctx, SD_EARG, "Chebyshev epilogue needs ComplexF64 phi_prev and psi_t");
+      epi = SD_EPI_CHEB; break;
+    default: return sd_set_err(ctx, SD_EARG, "unknown epilogue");
+  }
+  return sd_launch_apply(ctx, m, dtype, out, psi, epi, ea);
+}
+
 int sd_apply_rescaled_dev(sd_ctx *ctx, const sd_model *m, int dtype, void *out, const void *psi, int64_t n, double a,
                           double b) {
   int rc = check_apply_args(ctx, m, dtype, out, psi, n);

@@ -266,6 +266,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_apply_tiled(sd_dev_model dm, doubl
   double *red = reinterpret_cast<double *>(lbin + 16 * SD_BIN_STRIDE);
 
   const V *__restrict__ psi = reinterpret_cast<const V *>(psi_);
+  const V *__restrict__ halo = reinterpret_cast<const V *>(ea.halo);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int tix = blockIdx.x;
@@ -344,7 +345,9 @@ __global__ __launch_bounds__(BLOCK, 4) void k_apply_tiled(sd_dev_model dm, doubl
   };
   // rows outside [lo, lo+n) wrap to a huge unsigned offset or exceed n*ES: the load returns 0 and J*0 leaves acc unchanged
   auto issue = [&](const FarBond &fb, V(&v)[R]) {
-    const __amdgpu_buffer_rsrc_t rs = make_rsrc(psi + fb.base, (uint32_t)fb.n * ES);
+    // partner tile lives in the owned rows, or (sharded plans) in the halo imported from its owner
+    const V *__restrict__ pb = (halo && fb.base >= dm.n_local) ? halo + (fb.base - dm.n_local) : psi + fb.base;
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(pb, (uint32_t)fb.n * ES);
     const uint32_t lo_b = (uint32_t)fb.lo * ES;
 #pragma unroll
     for (int r = 0; r < R; ++r) buf_load(v[r], rs, ioff[r] - lo_b);
@@ -427,7 +430,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_apply_tiled(sd_dev_model dm, doubl
         if (((s >> bi) ^ (s >> bj)) & 1) {
           const uint64_t s2 = s ^ ((uint64_t)1 << bi) ^ ((uint64_t)1 << bj);
           const int64_t idx = dm.addr[(uint32_t)(s2 & pmask)] + dm.suf_rank[(uint32_t)(s2 >> p)];
-          acc[r] = accum<false>(acc[r], J, psi[idx]);
+          acc[r] = accum<false>(acc[r], J, (halo && idx >= dm.n_local) ? halo[idx - dm.n_local] : psi[idx]);
         }
       }
     }

@@ -1,8 +1,7 @@
 """world_size-2 (and 3) halo exchange over gloo on CPU: the N>1 communication path of spindynamics.jl_amd/dist.py
-(ShardedOperator.exchange) run with real torch.distributed send/recv on CPU tensors.  After the exchange the
-[owned | halo] buffer must hold psi at exactly the global rows the plan says, and a sharded apply emulated with
-the oracle on that buffer must equal the unsharded oracle apply (this checks the plan + exchange; the HIP kernel's
-use of the same buffer is checked on the GPU in test_gpu_sharded.py)."""
+(ShardedOperator.exchange) run with real torch.distributed send/recv on CPU tensors.  After the exchange the halo
+buffer must hold psi at exactly the global rows the plan says (this checks the plan + exchange; the HIP kernel's use
+of the same buffer is checked on the GPU in test_gpu_sharded.py), and the all-reduced norm must equal the global one."""
 import os
 import socket
 import sys
@@ -35,14 +34,15 @@ def _worker(rank, world, port, L, nup, q):
         op = pkg.ShardedOperator(m, rank, world)
         rng = np.random.default_rng(42)
         psi = rng.standard_normal(m.N) + 1j * rng.standard_normal(m.N)      # same on every rank
-        buf = torch.full((op.n_local + op.n_halo,), float("nan"), dtype=torch.complex128)
-        buf[: op.n_local] = torch.from_numpy(psi[op.row_lo:op.row_hi])
-        op.exchange(buf)
-        got = buf.numpy()
-        ok = bool(np.array_equal(got[: op.n_local], psi[op.row_lo:op.row_hi]))
-        for (_, lo, cnt, grow) in op.recv_slabs:
-            ok = ok and bool(np.array_equal(got[lo:lo + cnt], psi[grow:grow + cnt]))
-        nrm = op.norm(buf) if op.n_local else None
+        buf = torch.from_numpy(psi[op.row_lo:op.row_hi].copy())
+        op.halo(buf).fill_(float("nan"))
+        halo = op.exchange(buf).numpy()
+        ok = True
+        for (_, lo, cnt, grow) in op.recv_slabs:               # lo counts from the start of [owned | halo]
+            ok = ok and bool(np.array_equal(halo[lo - op.n_local:lo - op.n_local + cnt], psi[grow:grow + cnt]))
+        ok = ok and not bool(np.isnan(halo[: op.n_halo]).any())
+        nrm = op.norm(buf)
+        ok = ok and abs(nrm - float(np.linalg.norm(psi))) <= 1e-12 * float(np.linalg.norm(psi))
         dist.barrier()
         dist.destroy_process_group()
         q.put((rank, ok, op.n_local, op.n_halo, nrm, float(np.linalg.norm(psi))))
