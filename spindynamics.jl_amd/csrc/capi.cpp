@@ -12,6 +12,15 @@ int sd_set_err(sd_ctx *ctx, int code, const std::string &msg) {
   return code;
 }
 
+int sd_ensure_partials(sd_ctx *ctx, size_t doubles) {
+  if (ctx->partials_cap >= doubles) return SD_OK;
+  if (ctx->d_partials) (void)hipFree(ctx->d_partials);   // hipFree waits for the kernels still using it
+  ctx->d_partials = nullptr; ctx->partials_cap = 0;
+  SD_HIP(ctx, hipMalloc((void **)&ctx->d_partials, doubles * sizeof(double)));
+  ctx->partials_cap = doubles;
+  return SD_OK;
+}
+
 namespace {
 thread_local std::string g_err;  // errors raised without a context
 

@@ -22,182 +22,12 @@
 #include <algorithm>
 #include <cstdlib>
 
-#include "sd_internal.hpp"
+#include "device_common.hpp"
 
-#define SD_BIN_STRIDE 17
+
+using namespace sd_dev;
 
 namespace {
-
-template <int NC> struct VT;
-template <> struct VT<1> { using type = double; };
-template <> struct VT<2> { using type = double2; };
-
-__device__ __forceinline__ double vadd_mul(double acc, double J, double v) { return acc + J * v; }
-__device__ __forceinline__ double2 vadd_mul(double2 acc, double J, double2 v) {
-  return make_double2(acc.x + J * v.x, acc.y + J * v.y);
-}
-__device__ __forceinline__ double vscale(double d, double v) { return d * v; }
-__device__ __forceinline__ double2 vscale(double d, double2 v) { return make_double2(d * v.x, d * v.y); }
-
-__device__ __forceinline__ double sz_of(uint64_t bit) { return bit ? 0.5 : -0.5; }
-
-// diagonal matrix element for configuration s -- src/Hamiltonian.jl:226-241
-__device__ __forceinline__ double diag_of(const sd_dev_model &dm, uint64_t s) {
-  if (dm.diag_mode == 1) {
-    // uniform zz couplings whose partial sums are exact: sum of +-q == q*(n_par - n_anti)
-    int anti = 0, k0 = 0;
-    if (dm.n_zz_nn > 0) {
-      uint64_t x = (s ^ (s >> 1)) & (((uint64_t)1 << (dm.L - 1)) - 1);
-      anti = __popcll(x);
-      k0 = dm.n_zz_nn;
-    }
-    for (int k = k0; k < dm.n_zz; ++k)
-      anti += (int)(((s >> (dm.zz_i[k] - 1)) ^ (s >> (dm.zz_j[k] - 1))) & 1);
-    return dm.diag_q * (double)(dm.n_zz - 2 * anti);
-  }
-  double d = 0.0;
-  for (int i = 1; i <= dm.L; ++i) d += dm.field[i - 1] * sz_of((s >> (i - 1)) & 1);
-  for (int k = 0; k < dm.n_zz; ++k)
-    d += (dm.zz_J[k] * sz_of((s >> (dm.zz_i[k] - 1)) & 1)) * sz_of((s >> (dm.zz_j[k] - 1)) & 1);
-  return d;
-}
-
-__device__ __forceinline__ int64_t binom_g(const sd_dev_model &dm, int n, int k) {
-  return (k < 0 || k > n) ? 0 : dm.binom[n * (SD_MAX_L + 1) + k];
-}
-
-// combinadic unrank / rank in the reference order (generic path)
-__device__ __forceinline__ uint64_t unrank_g(const sd_dev_model &dm, int64_t idx) {
-  uint64_t s = 0;
-  int r = dm.nup;
-  for (int k = 1; k <= dm.L && r > 0; ++k) {
-    int64_t c = binom_g(dm, dm.L - k, r - 1);
-    if (idx < c) { s |= (uint64_t)1 << (k - 1); --r; }
-    else idx -= c;
-  }
-  return s;
-}
-__device__ __forceinline__ int64_t rank_g(const sd_dev_model &dm, uint64_t s) {
-  int64_t idx = 0;
-  int r = dm.nup;
-  for (int k = 1; k <= dm.L && r > 0; ++k) {
-    if ((s >> (k - 1)) & 1) --r;
-    else idx += binom_g(dm, dm.L - k, r - 1);
-  }
-  return idx;
-}
-
-// ---- epilogue: what is stored for row `row` given acc = (H psi)[row] ----
-struct EpiSums { double s0, s1; };
-
-template <int NC>
-__device__ __forceinline__ void epilogue(int epi, const sd_epi_args &ea, int64_t row, typename VT<NC>::type acc,
-                                         typename VT<NC>::type own, double *out, EpiSums &sums);
-
-template <>
-__device__ __forceinline__ void epilogue<1>(int epi, const sd_epi_args &ea, int64_t row, double acc, double own,
-                                            double *out, EpiSums &sums) {
-  switch (epi) {
-    case SD_EPI_PLAIN:
-      out[row] = ea.negate ? -acc : acc;
-      break;
-    case SD_EPI_DOT: {
-      double o = ea.negate ? -acc : acc;
-      out[row] = o;
-      sums.s0 += own * o;
-    } break;
-    case SD_EPI_RESCALE:
-      out[row] = (acc - ea.b * own) / ea.a;
-      break;
-    case SD_EPI_RESCALE_DOT: {
-      double o = (acc - ea.b * own) / ea.a;
-      out[row] = o;
-      double ph = ((const double *)ea.phi)[row];
-      sums.s0 += ph * o;
-      sums.s1 += o * o;
-    } break;
-    case SD_EPI_KPM: {
-      double o = 2.0 * ((acc - ea.b * own) / ea.a) - ((const double *)ea.prev)[row];
-      out[row] = o;
-      double ph = ((const double *)ea.phi)[row];
-      sums.s0 += ph * o;
-      sums.s1 += o * o;
-    } break;
-    default: {  // SD_EPI_CHEB on real vectors: real accumulate with real coefficient
-      double o = 2.0 * ((acc - ea.b * own) / ea.a) - ((const double *)ea.prev)[row];
-      out[row] = o;
-      double *pt = (double *)ea.accv;
-      pt[row] += ea.c_re * o;
-    } break;
-  }
-}
-
-template <>
-__device__ __forceinline__ void epilogue<2>(int epi, const sd_epi_args &ea, int64_t row, double2 acc, double2 own,
-                                            double *out, EpiSums &sums) {
-  double2 *o2 = (double2 *)out;
-  switch (epi) {
-    case SD_EPI_PLAIN:
-      o2[row] = ea.negate ? make_double2(-acc.x, -acc.y) : acc;
-      break;
-    case SD_EPI_DOT: {
-      double2 o = ea.negate ? make_double2(-acc.x, -acc.y) : acc;
-      o2[row] = o;
-      sums.s0 += own.x * o.x + own.y * o.y;   // conj(own) * o
-      sums.s1 += own.x * o.y - own.y * o.x;
-    } break;
-    case SD_EPI_RESCALE:
-      o2[row] = make_double2((acc.x - ea.b * own.x) / ea.a, (acc.y - ea.b * own.y) / ea.a);
-      break;
-    case SD_EPI_RESCALE_DOT: {
-      double2 o = make_double2((acc.x - ea.b * own.x) / ea.a, (acc.y - ea.b * own.y) / ea.a);
-      o2[row] = o;
-      double2 ph = ((const double2 *)ea.phi)[row];
-      sums.s0 += ph.x * o.x + ph.y * o.y;     // Re <phi|o>
-      sums.s1 += o.x * o.x + o.y * o.y;
-    } break;
-    case SD_EPI_KPM: {
-      double2 pv = ((const double2 *)ea.prev)[row];
-      double2 o = make_double2(2.0 * ((acc.x - ea.b * own.x) / ea.a) - pv.x,
-                               2.0 * ((acc.y - ea.b * own.y) / ea.a) - pv.y);
-      o2[row] = o;
-      double2 ph = ((const double2 *)ea.phi)[row];
-      sums.s0 += ph.x * o.x + ph.y * o.y;
-      sums.s1 += o.x * o.x + o.y * o.y;
-    } break;
-    default: {  // SD_EPI_CHEB  (src/TimeEvolution/Chebyshev.jl:112-117)
-      double2 pv = ((const double2 *)ea.prev)[row];
-      double2 o = make_double2(2.0 * ((acc.x - ea.b * own.x) / ea.a) - pv.x,
-                               2.0 * ((acc.y - ea.b * own.y) / ea.a) - pv.y);
-      o2[row] = o;
-      double2 *pt = (double2 *)ea.accv;
-      double2 t = pt[row];
-      t.x += ea.c_re * o.x - ea.c_im * o.y;
-      t.y += ea.c_re * o.y + ea.c_im * o.x;
-      pt[row] = t;
-    } break;
-  }
-}
-
-// deterministic block reduction of two doubles; result valid in thread 0
-__device__ __forceinline__ void block_reduce2(double &a, double &b, double *red /* >= 2*16 doubles LDS */) {
-  for (int off = 32; off > 0; off >>= 1) {
-    a += __shfl_down(a, off, 64);
-    b += __shfl_down(b, off, 64);
-  }
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
-  if (lane == 0) { red[2 * wv] = a; red[2 * wv + 1] = b; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double x = 0.0, y = 0.0;
-    for (int w = 0; w < nw; ++w) { x += red[2 * w]; y += red[2 * w + 1]; }
-    a = x; b = y;
-  }
-}
-
-__device__ __forceinline__ bool epi_has_sums(int epi) {
-  return epi == SD_EPI_DOT || epi == SD_EPI_KPM || epi == SD_EPI_RESCALE_DOT;
-}
 
 // =====================================================================
 // tiled kernel
@@ -217,43 +47,6 @@ __device__ __forceinline__ bool epi_has_sums(int epi) {
 // Accumulation order per row is the reference's bond order 1..L-1.  When every
 // NN hop amplitude is a power of two (XXZChain default 0.5) J*psi is exact and
 // acc + J*psi is evaluated with one fma (bit-identical to the unfused form).
-template <bool FMA>
-__device__ __forceinline__ double acc1(double acc, double J, double v) {
-  return FMA ? __builtin_fma(J, v, acc) : acc + J * v;
-}
-template <bool FMA>
-__device__ __forceinline__ double accum(double acc, double J, double v) { return acc1<FMA>(acc, J, v); }
-template <bool FMA>
-__device__ __forceinline__ double2 accum(double2 acc, double J, double2 v) {
-  return make_double2(acc1<FMA>(acc.x, J, v.x), acc1<FMA>(acc.y, J, v.y));
-}
-
-__device__ __forceinline__ int rl(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
-__device__ __forceinline__ int64_t rl64(int64_t v, int lane) {
-  const uint32_t lo = (uint32_t)rl((int)(uint32_t)v, lane), hi = (uint32_t)rl((int)(uint32_t)((uint64_t)v >> 32), lane);
-  return (int64_t)(((uint64_t)hi << 32) | lo);
-}
-__device__ __forceinline__ double rld(double v, int lane) { return __longlong_as_double(rl64(__double_as_longlong(v), lane)); }
-
-struct FarBond { int64_t base; double J; int lo, n; };   // partner rows: psi[base + (i - lo)] for lo <= i < lo + n
-
-// 128-bit buffer descriptor over [p, p + bytes): loads with a byte offset >= bytes return 0 (hardware range check),
-// which replaces every per-row "is this row in range" test of the far-bond streams.
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, uint32_t bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
-}
-__device__ __forceinline__ void buf_load(double &v, __amdgpu_buffer_rsrc_t r, uint32_t off) {
-  typedef unsigned int u2 __attribute__((ext_vector_type(2)));
-  const u2 raw = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0);
-  v = __hiloint2double((int)raw.y, (int)raw.x);
-}
-__device__ __forceinline__ void buf_load(double2 &v, __amdgpu_buffer_rsrc_t r, uint32_t off) {
-  typedef unsigned int u4 __attribute__((ext_vector_type(4)));
-  const u4 raw = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
-  v.x = __hiloint2double((int)raw.y, (int)raw.x);
-  v.y = __hiloint2double((int)raw.w, (int)raw.z);
-}
-
 template <int NC, int R, int BLOCK, bool FMA, bool DIAG = false>
 __global__ __launch_bounds__(BLOCK, 4) void k_apply_tiled(sd_dev_model dm, double *__restrict__ out_,
                                                        const double *__restrict__ psi_, int epi, sd_epi_args ea,
@@ -692,140 +485,6 @@ __global__ __launch_bounds__(1024) void k_reduce_pairs(const double *__restrict_
   if (threadIdx.x == 0) { scalars[0] = a; scalars[1] = b; }
 }
 
-// =====================================================================
-// Sz_q_vector  (src/Hamiltonian.jl:307-337)
-// =====================================================================
-struct SzqPhases { double re[SD_MAX_L + 1], im[SD_MAX_L + 1]; };
-
-template <int NCIN>
-__device__ __forceinline__ void szq_row(const sd_dev_model &dm, const SzqPhases &ph, double normfact, uint64_t s,
-                                        const double *__restrict__ psi0, int64_t row, double2 *__restrict__ phi) {
-  double sr = 0.0, si = 0.0;
-  for (int r = 0; r < dm.L; ++r) {
-    const double z = sz_of((s >> r) & 1);
-    sr += ph.re[r] * z;
-    si += ph.im[r] * z;
-  }
-  const double ar = normfact * sr, ai = normfact * si;
-  double xr, xi;
-  if (NCIN == 2) { xr = psi0[2 * row]; xi = psi0[2 * row + 1]; }
-  else { xr = psi0[row]; xi = 0.0; }
-  phi[row] = make_double2(ar * xr - ai * xi, ar * xi + ai * xr);
-}
-
-template <int NCIN>
-__global__ __launch_bounds__(256) void k_szq_tiled(sd_dev_model dm, SzqPhases ph, double normfact,
-                                                   const double *__restrict__ psi0, double2 *__restrict__ phi) {
-  const int tix = blockIdx.x;
-  const uint32_t P = dm.tile_prefix[tix];
-  const int64_t base = dm.tile_base[tix];
-  const int t2 = dm.nup - __popc(P);
-  const int len = (int)binom_g(dm, dm.LS, t2);
-  const uint16_t *__restrict__ sufS = dm.suf_states + dm.suf_off[t2];
-  for (int i = threadIdx.x; i < len; i += blockDim.x) {
-    const uint64_t s = (uint64_t)P | ((uint64_t)sufS[i] << dm.p);
-    szq_row<NCIN>(dm, ph, normfact, s, psi0, base + i, phi);
-  }
-}
-
-template <int NCIN>
-__global__ __launch_bounds__(256) void k_szq_generic(sd_dev_model dm, SzqPhases ph, double normfact,
-                                                     const double *__restrict__ psi0, double2 *__restrict__ phi) {
-  const bool full = dm.nup < 0;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < dm.N; idx += stride) {
-    const uint64_t s = full ? (uint64_t)idx : unrank_g(dm, idx);
-    szq_row<NCIN>(dm, ph, normfact, s, psi0, idx, phi);
-  }
-}
-
-
-// =====================================================================
-// Observables ("next" row f2): magnetization_per_site (src/Observables.jl:14-36) and the lag sums needed by
-// connected_correlations (:44-94).  The reference accumulates the full L x L matrix <S_i S_j>; C_r only needs
-//   R_r = sum_i <S_i S_{mod1(i+r,L)}> = sum_rows |psi|^2 * (L - 2*popcount(s XOR rot_r(s)))/4
-// (rot_r = cyclic rotation of the L-bit configuration), i.e. L sums instead of L^2.  One read stream of psi per
-// chunk of 16 accumulators; per-thread register accumulators, fixed-order two-stage reduction (deterministic).
-// =====================================================================
-#define SD_OBS_CHUNK 16
-template <int NC, int MODE>
-__device__ __forceinline__ void obs_row(const sd_dev_model &dm, uint64_t s, const double *__restrict__ psi, int64_t row,
-                                        int c0, int cn, double (&acc)[SD_OBS_CHUNK]) {
-  double prob;
-  if (NC == 2) { const double2 v = ((const double2 *)psi)[row]; prob = v.x * v.x + v.y * v.y; }
-  else { const double v = psi[row]; prob = v * v; }
-  if (prob == 0.0) return;                                     // src/Observables.jl:21,53
-  const int L = dm.L;
-  const uint64_t mask = L >= 64 ? ~(uint64_t)0 : (((uint64_t)1 << L) - 1);
-#pragma unroll
-  for (int k = 0; k < SD_OBS_CHUNK; ++k) {
-    if (k < cn) {
-      const int c = c0 + k;
-      if (MODE == 0) acc[k] += prob * sz_of((s >> c) & 1);
-      else {
-        const uint64_t rot = c == 0 ? s : (((s >> c) | (s << (L - c))) & mask);
-        acc[k] += prob * (0.25 * (double)(L - 2 * (int)__popcll(s ^ rot)));
-      }
-    }
-  }
-}
-
-template <int NC, int MODE>
-__global__ __launch_bounds__(256) void k_obs(sd_dev_model dm, const double *__restrict__ psi, int c0, int cn,
-                                             double *__restrict__ partials) {
-  __shared__ double red[32];
-  double acc[SD_OBS_CHUNK];
-#pragma unroll
-  for (int k = 0; k < SD_OBS_CHUNK; ++k) acc[k] = 0.0;
-  if (dm.p >= 0) {
-    for (int t = blockIdx.x; t < dm.n_tiles; t += gridDim.x) {
-      const uint32_t P = dm.tile_prefix[t];
-      const int64_t base = dm.tile_base[t];
-      const int t2 = dm.nup - __popc(P);
-      const int len = (int)binom_g(dm, dm.LS, t2);
-      const uint16_t *__restrict__ sufS = dm.suf_states + dm.suf_off[t2];
-      for (int i = threadIdx.x; i < len; i += blockDim.x)
-        obs_row<NC, MODE>(dm, (uint64_t)P | ((uint64_t)sufS[i] << dm.p), psi, base + i, c0, cn, acc);
-    }
-  } else {
-    const bool full = dm.nup < 0;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < dm.N; idx += stride)
-      obs_row<NC, MODE>(dm, full ? (uint64_t)idx : unrank_g(dm, idx), psi, idx, c0, cn, acc);
-  }
-#pragma unroll
-  for (int k = 0; k < SD_OBS_CHUNK; k += 2) {
-    double a = acc[k], b = acc[k + 1];
-    block_reduce2(a, b, red);
-    if (threadIdx.x == 0) { partials[(size_t)blockIdx.x * SD_OBS_CHUNK + k] = a; partials[(size_t)blockIdx.x * SD_OBS_CHUNK + k + 1] = b; }
-    __syncthreads();
-  }
-}
-
-__global__ __launch_bounds__(256) void k_obs_reduce(const double *__restrict__ partials, int nblocks, double *__restrict__ out) {
-  // thread (k, j): accumulator k, blocks j, j+16, ... ; then a fixed-order sum over j
-  __shared__ double sm[16][SD_OBS_CHUNK];
-  const int k = threadIdx.x & 15, j = threadIdx.x >> 4;
-  double a = 0.0;
-  for (int b = j; b < nblocks; b += 16) a += partials[(size_t)b * SD_OBS_CHUNK + k];
-  sm[j][k] = a;
-  __syncthreads();
-  if (threadIdx.x < SD_OBS_CHUNK) {
-    double t = 0.0;
-    for (int jj = 0; jj < 16; ++jj) t += sm[jj][threadIdx.x];
-    out[threadIdx.x] = t;
-  }
-}
-
-int ensure_partials(sd_ctx *ctx, size_t doubles) {
-  if (ctx->partials_cap >= doubles) return SD_OK;
-  if (ctx->d_partials) (void)hipFree(ctx->d_partials);
-  ctx->d_partials = nullptr; ctx->partials_cap = 0;
-  SD_HIP(ctx, hipMalloc((void **)&ctx->d_partials, doubles * sizeof(double)));
-  ctx->partials_cap = doubles;
-  return SD_OK;
-}
-
 template <int NC, int R, int BLOCK, bool FMA>
 int launch_tiled_cfg(sd_ctx *ctx, const sd_dev_model &dm, int nt, size_t shmem, double *out, const double *psi, int epi,
                      const sd_epi_args &ea, int max_len) {
@@ -865,7 +524,7 @@ int sd_launch_apply(sd_ctx *ctx, const sd_model *m, int dtype, void *out, const 
   if (dm.n_local == 0) return SD_OK;
   if (m->p >= 0) {
     const int nt = dm.n_singles, ng = dm.n_groups;
-    if (sums) { int rc = ensure_partials(ctx, 2 * (size_t)(nt + ng)); if (rc) return rc; }
+    if (sums) { int rc = sd_ensure_partials(ctx, 2 * (size_t)(nt + ng)); if (rc) return rc; }
     const int max_len = m->max_tile_len;
     const size_t esz = dtype == SD_C128 ? 16 : 8;
     int rc = SD_OK;
@@ -904,7 +563,7 @@ int sd_launch_apply(sd_ctx *ctx, const sd_model *m, int dtype, void *out, const 
   } else {
     int64_t nb = (dm.N + 255) / 256;
     if (nb > 8192) nb = 8192;
-    if (sums) { int rc = ensure_partials(ctx, 2 * (size_t)nb); if (rc) return rc; }
+    if (sums) { int rc = sd_ensure_partials(ctx, 2 * (size_t)nb); if (rc) return rc; }
     if (dtype == SD_C128)
       hipLaunchKernelGGL(k_apply_generic<2>, dim3((unsigned)nb), dim3(256), 0, ctx->stream, dm, (double *)out,
                          (const double *)psi, epi, ea, ctx->d_partials);
@@ -921,60 +580,3 @@ int sd_launch_apply(sd_ctx *ctx, const sd_model *m, int dtype, void *out, const 
 }
 
 
-// mode 0: out[L] = magnetization per site; mode 1: out[L] = lag sums R_r.  psi is a device vector.
-int sd_launch_observable(sd_ctx *ctx, const sd_model *m, int dtype, const void *psi, int mode, double *out_host) {
-  if (!m->dev_ready) return sd_set_err(ctx, SD_EARG, "model has no device tables (created without a context)");
-  if (dtype != SD_F64 && dtype != SD_C128) return sd_set_err(ctx, SD_EARG, "dtype must be SD_F64 or SD_C128");
-  const sd_dev_model &dm = m->dm;
-  int nb = m->p >= 0 ? std::min(dm.n_tiles, 2048) : (int)std::min<int64_t>(2048, (dm.N + 255) / 256);
-  if (nb < 1) nb = 1;
-  int rc = ensure_partials(ctx, (size_t)nb * SD_OBS_CHUNK);
-  if (rc) return rc;
-  for (int c0 = 0; c0 < dm.L; c0 += SD_OBS_CHUNK) {
-    const int cn = std::min(SD_OBS_CHUNK, dm.L - c0);
-    if (dtype == SD_C128) {
-      if (mode == 0) hipLaunchKernelGGL((k_obs<2, 0>), dim3(nb), dim3(256), 0, ctx->stream, dm, (const double *)psi, c0, cn, ctx->d_partials);
-      else hipLaunchKernelGGL((k_obs<2, 1>), dim3(nb), dim3(256), 0, ctx->stream, dm, (const double *)psi, c0, cn, ctx->d_partials);
-    } else {
-      if (mode == 0) hipLaunchKernelGGL((k_obs<1, 0>), dim3(nb), dim3(256), 0, ctx->stream, dm, (const double *)psi, c0, cn, ctx->d_partials);
-      else hipLaunchKernelGGL((k_obs<1, 1>), dim3(nb), dim3(256), 0, ctx->stream, dm, (const double *)psi, c0, cn, ctx->d_partials);
-    }
-    hipLaunchKernelGGL(k_obs_reduce, dim3(1), dim3(256), 0, ctx->stream, ctx->d_partials, nb, ctx->d_scalars);
-    SD_HIP(ctx, hipGetLastError());
-    double tmp[SD_OBS_CHUNK];
-    rc = sd_read_scalars(ctx, 0, SD_OBS_CHUNK, tmp);
-    if (rc) return rc;
-    for (int k = 0; k < cn; ++k) out_host[c0 + k] = tmp[k];
-  }
-  return SD_OK;
-}
-
-int sd_launch_szq(sd_ctx *ctx, const sd_model *m, int dtype_in, const void *psi0, double q, void *phi) {
-  if (!m->dev_ready) return sd_set_err(ctx, SD_EARG, "model has no device tables (created without a context)");
-  if (dtype_in != SD_F64 && dtype_in != SD_C128) return sd_set_err(ctx, SD_EARG, "dtype must be SD_F64 or SD_C128");
-  const sd_dev_model &dm = m->dm;
-  if (dm.n_local == 0) return SD_OK;
-  SzqPhases ph;
-  // phases = exp.(im*q*(0:L-1))  (src/Hamiltonian.jl:317), computed on the host in double
-  for (int r = 0; r < dm.L; ++r) { double x = q * (double)r; ph.re[r] = cos(x); ph.im[r] = sin(x); }
-  const double normfact = 1.0 / sqrt((double)dm.L);
-  if (m->p >= 0) {
-    if (dtype_in == SD_C128)
-      hipLaunchKernelGGL(k_szq_tiled<2>, dim3(dm.n_tiles), dim3(256), 0, ctx->stream, dm, ph, normfact,
-                         (const double *)psi0, (double2 *)phi);
-    else
-      hipLaunchKernelGGL(k_szq_tiled<1>, dim3(dm.n_tiles), dim3(256), 0, ctx->stream, dm, ph, normfact,
-                         (const double *)psi0, (double2 *)phi);
-  } else {
-    int64_t nb = (dm.N + 255) / 256;
-    if (nb > 8192) nb = 8192;
-    if (dtype_in == SD_C128)
-      hipLaunchKernelGGL(k_szq_generic<2>, dim3((unsigned)nb), dim3(256), 0, ctx->stream, dm, ph, normfact,
-                         (const double *)psi0, (double2 *)phi);
-    else
-      hipLaunchKernelGGL(k_szq_generic<1>, dim3((unsigned)nb), dim3(256), 0, ctx->stream, dm, ph, normfact,
-                         (const double *)psi0, (double2 *)phi);
-  }
-  SD_HIP(ctx, hipGetLastError());
-  return SD_OK;
-}

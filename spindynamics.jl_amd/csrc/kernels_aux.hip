@@ -1,0 +1,198 @@
+// Auxiliary kernels of the hot path: Sz_q_vector (src/Hamiltonian.jl:307-337) and the Observables reductions
+// (src/Observables.jl:14-109).  Single-stream passes over psi with the state decoded from the tile tables.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+
+#include "device_common.hpp"
+
+using namespace sd_dev;
+
+namespace {
+
+// =====================================================================
+// Sz_q_vector  (src/Hamiltonian.jl:307-337)
+// =====================================================================
+struct SzqPhases { double re[SD_MAX_L + 1], im[SD_MAX_L + 1]; };
+
+template <int NCIN>
+__device__ __forceinline__ void szq_row(const sd_dev_model &dm, const SzqPhases &ph, double normfact, uint64_t s,
+                                        const double *__restrict__ psi0, int64_t row, double2 *__restrict__ phi) {
+  double sr = 0.0, si = 0.0;
+  for (int r = 0; r < dm.L; ++r) {
+    const double z = sz_of((s >> r) & 1);
+    sr += ph.re[r] * z;
+    si += ph.im[r] * z;
+  }
+  const double ar = normfact * sr, ai = normfact * si;
+  double xr, xi;
+  if (NCIN == 2) { xr = psi0[2 * row]; xi = psi0[2 * row + 1]; }
+  else { xr = psi0[row]; xi = 0.0; }
+  phi[row] = make_double2(ar * xr - ai * xi, ar * xi + ai * xr);
+}
+
+template <int NCIN>
+__global__ __launch_bounds__(256) void k_szq_tiled(sd_dev_model dm, SzqPhases ph, double normfact,
+                                                   const double *__restrict__ psi0, double2 *__restrict__ phi) {
+  const int tix = blockIdx.x;
+  const uint32_t P = dm.tile_prefix[tix];
+  const int64_t base = dm.tile_base[tix];
+  const int t2 = dm.nup - __popc(P);
+  const int len = (int)binom_g(dm, dm.LS, t2);
+  const uint16_t *__restrict__ sufS = dm.suf_states + dm.suf_off[t2];
+  for (int i = threadIdx.x; i < len; i += blockDim.x) {
+    const uint64_t s = (uint64_t)P | ((uint64_t)sufS[i] << dm.p);
+    szq_row<NCIN>(dm, ph, normfact, s, psi0, base + i, phi);
+  }
+}
+
+template <int NCIN>
+__global__ __launch_bounds__(256) void k_szq_generic(sd_dev_model dm, SzqPhases ph, double normfact,
+                                                     const double *__restrict__ psi0, double2 *__restrict__ phi) {
+  const bool full = dm.nup < 0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < dm.N; idx += stride) {
+    const uint64_t s = full ? (uint64_t)idx : unrank_g(dm, idx);
+    szq_row<NCIN>(dm, ph, normfact, s, psi0, idx, phi);
+  }
+}
+
+
+// =====================================================================
+// Observables ("next" row f2): magnetization_per_site (src/Observables.jl:14-36) and the lag sums needed by
+// connected_correlations (:44-94).  The reference accumulates the full L x L matrix <S_i S_j>; C_r only needs
+//   R_r = sum_i <S_i S_{mod1(i+r,L)}> = sum_rows |psi|^2 * (L - 2*popcount(s XOR rot_r(s)))/4
+// (rot_r = cyclic rotation of the L-bit configuration), i.e. L sums instead of L^2.  One read stream of psi per
+// chunk of 16 accumulators; per-thread register accumulators, fixed-order two-stage reduction (deterministic).
+// =====================================================================
+#define SD_OBS_CHUNK 16
+template <int NC, int MODE>
+__device__ __forceinline__ void obs_row(const sd_dev_model &dm, uint64_t s, const double *__restrict__ psi, int64_t row,
+                                        int c0, int cn, double (&acc)[SD_OBS_CHUNK]) {
+  double prob;
+  if (NC == 2) { const double2 v = ((const double2 *)psi)[row]; prob = v.x * v.x + v.y * v.y; }
+  else { const double v = psi[row]; prob = v * v; }
+  if (prob == 0.0) return;                                     // src/Observables.jl:21,53
+  const int L = dm.L;
+  const uint64_t mask = L >= 64 ? ~(uint64_t)0 : (((uint64_t)1 << L) - 1);
+#pragma unroll
+  for (int k = 0; k < SD_OBS_CHUNK; ++k) {
+    if (k < cn) {
+      const int c = c0 + k;
+      if (MODE == 0) acc[k] += prob * sz_of((s >> c) & 1);
+      else {
+        const uint64_t rot = c == 0 ? s : (((s >> c) | (s << (L - c))) & mask);
+        acc[k] += prob * (0.25 * (double)(L - 2 * (int)__popcll(s ^ rot)));
+      }
+    }
+  }
+}
+
+template <int NC, int MODE>
+__global__ __launch_bounds__(256) void k_obs(sd_dev_model dm, const double *__restrict__ psi, int c0, int cn,
+                                             double *__restrict__ partials) {
+  __shared__ double red[32];
+  double acc[SD_OBS_CHUNK];
+#pragma unroll
+  for (int k = 0; k < SD_OBS_CHUNK; ++k) acc[k] = 0.0;
+  if (dm.p >= 0) {
+    for (int t = blockIdx.x; t < dm.n_tiles; t += gridDim.x) {
+      const uint32_t P = dm.tile_prefix[t];
+      const int64_t base = dm.tile_base[t];
+      const int t2 = dm.nup - __popc(P);
+      const int len = (int)binom_g(dm, dm.LS, t2);
+      const uint16_t *__restrict__ sufS = dm.suf_states + dm.suf_off[t2];
+      for (int i = threadIdx.x; i < len; i += blockDim.x)
+        obs_row<NC, MODE>(dm, (uint64_t)P | ((uint64_t)sufS[i] << dm.p), psi, base + i, c0, cn, acc);
+    }
+  } else {
+    const bool full = dm.nup < 0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < dm.N; idx += stride)
+      obs_row<NC, MODE>(dm, full ? (uint64_t)idx : unrank_g(dm, idx), psi, idx, c0, cn, acc);
+  }
+#pragma unroll
+  for (int k = 0; k < SD_OBS_CHUNK; k += 2) {
+    double a = acc[k], b = acc[k + 1];
+    block_reduce2(a, b, red);
+    if (threadIdx.x == 0) { partials[(size_t)blockIdx.x * SD_OBS_CHUNK + k] = a; partials[(size_t)blockIdx.x * SD_OBS_CHUNK + k + 1] = b; }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void k_obs_reduce(const double *__restrict__ partials, int nblocks, double *__restrict__ out) {
+  // thread (k, j): accumulator k, blocks j, j+16, ... ; then a fixed-order sum over j
+  __shared__ double sm[16][SD_OBS_CHUNK];
+  const int k = threadIdx.x & 15, j = threadIdx.x >> 4;
+  double a = 0.0;
+  for (int b = j; b < nblocks; b += 16) a += partials[(size_t)b * SD_OBS_CHUNK + k];
+  sm[j][k] = a;
+  __syncthreads();
+  if (threadIdx.x < SD_OBS_CHUNK) {
+    double t = 0.0;
+    for (int jj = 0; jj < 16; ++jj) t += sm[jj][threadIdx.x];
+    out[threadIdx.x] = t;
+  }
+}
+
+
+}  // namespace
+
+// mode 0: out[L] = magnetization per site; mode 1: out[L] = lag sums R_r.  psi is a device vector.
+int sd_launch_observable(sd_ctx *ctx, const sd_model *m, int dtype, const void *psi, int mode, double *out_host) {
+  if (!m->dev_ready) return sd_set_err(ctx, SD_EARG, "model has no device tables (created without a context)");
+  if (dtype != SD_F64 && dtype != SD_C128) return sd_set_err(ctx, SD_EARG, "dtype must be SD_F64 or SD_C128");
+  const sd_dev_model &dm = m->dm;
+  int nb = m->p >= 0 ? std::min(dm.n_tiles, 2048) : (int)std::min<int64_t>(2048, (dm.N + 255) / 256);
+  if (nb < 1) nb = 1;
+  int rc = sd_ensure_partials(ctx, (size_t)nb * SD_OBS_CHUNK);
+  if (rc) return rc;
+  for (int c0 = 0; c0 < dm.L; c0 += SD_OBS_CHUNK) {
+    const int cn = std::min(SD_OBS_CHUNK, dm.L - c0);
+    if (dtype == SD_C128) {
+      if (mode == 0) hipLaunchKernelGGL((k_obs<2, 0>), dim3(nb), dim3(256), 0, ctx->stream, dm, (const double *)psi, c0, cn, ctx->d_partials);
+      else hipLaunchKernelGGL((k_obs<2, 1>), dim3(nb), dim3(256), 0, ctx->stream, dm, (const double *)psi, c0, cn, ctx->d_partials);
+    } else {
+      if (mode == 0) hipLaunchKernelGGL((k_obs<1, 0>), dim3(nb), dim3(256), 0, ctx->stream, dm, (const double *)psi, c0, cn, ctx->d_partials);
+      else hipLaunchKernelGGL((k_obs<1, 1>), dim3(nb), dim3(256), 0, ctx->stream, dm, (const double *)psi, c0, cn, ctx->d_partials);
+    }
+    hipLaunchKernelGGL(k_obs_reduce, dim3(1), dim3(256), 0, ctx->stream, ctx->d_partials, nb, ctx->d_scalars);
+    SD_HIP(ctx, hipGetLastError());
+    double tmp[SD_OBS_CHUNK];
+    rc = sd_read_scalars(ctx, 0, SD_OBS_CHUNK, tmp);
+    if (rc) return rc;
+    for (int k = 0; k < cn; ++k) out_host[c0 + k] = tmp[k];
+  }
+  return SD_OK;
+}
+
+int sd_launch_szq(sd_ctx *ctx, const sd_model *m, int dtype_in, const void *psi0, double q, void *phi) {
+  if (!m->dev_ready) return sd_set_err(ctx, SD_EARG, "model has no device tables (created without a context)");
+  if (dtype_in != SD_F64 && dtype_in != SD_C128) return sd_set_err(ctx, SD_EARG, "dtype must be SD_F64 or SD_C128");
+  const sd_dev_model &dm = m->dm;
+  if (dm.n_local == 0) return SD_OK;
+  SzqPhases ph;
+  // phases = exp.(im*q*(0:L-1))  (src/Hamiltonian.jl:317), computed on the host in double
+  for (int r = 0; r < dm.L; ++r) { double x = q * (double)r; ph.re[r] = cos(x); ph.im[r] = sin(x); }
+  const double normfact = 1.0 / sqrt((double)dm.L);
+  if (m->p >= 0) {
+    if (dtype_in == SD_C128)
+      hipLaunchKernelGGL(k_szq_tiled<2>, dim3(dm.n_tiles), dim3(256), 0, ctx->stream, dm, ph, normfact,
+                         (const double *)psi0, (double2 *)phi);
+    else
+      hipLaunchKernelGGL(k_szq_tiled<1>, dim3(dm.n_tiles), dim3(256), 0, ctx->stream, dm, ph, normfact,
+                         (const double *)psi0, (double2 *)phi);
+  } else {
+    int64_t nb = (dm.N + 255) / 256;
+    if (nb > 8192) nb = 8192;
+    if (dtype_in == SD_C128)
+      hipLaunchKernelGGL(k_szq_generic<2>, dim3((unsigned)nb), dim3(256), 0, ctx->stream, dm, ph, normfact,
+                         (const double *)psi0, (double2 *)phi);
+    else
+      hipLaunchKernelGGL(k_szq_generic<1>, dim3((unsigned)nb), dim3(256), 0, ctx->stream, dm, ph, normfact,
+                         (const double *)psi0, (double2 *)phi);
+  }
+  SD_HIP(ctx, hipGetLastError());
+  return SD_OK;
+}

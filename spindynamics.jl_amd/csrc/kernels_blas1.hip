@@ -5,27 +5,14 @@
 // two-stage with a fixed order (deterministic run to run).
 #include <hip/hip_runtime.h>
 
-#include "sd_internal.hpp"
+#include "device_common.hpp"
+
+using sd_dev::block_reduce2;
 
 namespace {
 
 constexpr int RED_BLOCKS = 2048;
 constexpr int BS = 256;
-
-__device__ __forceinline__ void block_reduce2(double &a, double &b, double *red) {
-  for (int off = 32; off > 0; off >>= 1) {
-    a += __shfl_down(a, off, 64);
-    b += __shfl_down(b, off, 64);
-  }
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
-  if (lane == 0) { red[2 * wv] = a; red[2 * wv + 1] = b; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double x = 0.0, y = 0.0;
-    for (int w = 0; w < nw; ++w) { x += red[2 * w]; y += red[2 * w + 1]; }
-    a = x; b = y;
-  }
-}
 
 // conj(x).y for complex (nc=2) or x.y for real (nc=1); n2 = number of double2 elements when vectorised
 template <int NC>
@@ -217,21 +204,12 @@ inline unsigned grid_for(int64_t n) {
   return (unsigned)nb;
 }
 
-int ensure_partials(sd_ctx *ctx, size_t doubles) {
-  if (ctx->partials_cap >= doubles) return SD_OK;
-  if (ctx->d_partials) (void)hipFree(ctx->d_partials);
-  ctx->d_partials = nullptr; ctx->partials_cap = 0;
-  SD_HIP(ctx, hipMalloc((void **)&ctx->d_partials, doubles * sizeof(double)));
-  ctx->partials_cap = doubles;
-  return SD_OK;
-}
-
 }  // namespace
 
 double sd_randn_host(uint64_t seed, uint64_t k) { return randn_at(seed, k); }
 
 int sd_k_dot(sd_ctx *ctx, int nc, const double *x, const double *y, int64_t N, int slot) {
-  int rc = ensure_partials(ctx, 2 * RED_BLOCKS); if (rc) return rc;
+  int rc = sd_ensure_partials(ctx, 2 * RED_BLOCKS); if (rc) return rc;
   int nb = (int)std::min<int64_t>(RED_BLOCKS, std::max<int64_t>(1, (N + BS - 1) / BS));
   if (nc == 2) hipLaunchKernelGGL(k_dot<2>, dim3(nb), dim3(BS), 0, ctx->stream, x, y, N, ctx->d_partials);
   else hipLaunchKernelGGL(k_dot<1>, dim3(nb), dim3(BS), 0, ctx->stream, x, y, N, ctx->d_partials);
@@ -241,7 +219,7 @@ int sd_k_dot(sd_ctx *ctx, int nc, const double *x, const double *y, int64_t N, i
 }
 
 int sd_k_nrm2sq(sd_ctx *ctx, const double *x, int64_t n, int slot) {
-  int rc = ensure_partials(ctx, 2 * RED_BLOCKS); if (rc) return rc;
+  int rc = sd_ensure_partials(ctx, 2 * RED_BLOCKS); if (rc) return rc;
   int nb = (int)std::min<int64_t>(RED_BLOCKS, std::max<int64_t>(1, (n + BS - 1) / BS));
   hipLaunchKernelGGL(k_nrm2sq, dim3(nb), dim3(BS), 0, ctx->stream, x, n, ctx->d_partials);
   hipLaunchKernelGGL(k_reduce_to, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_partials, nb, ctx->d_scalars + slot);
@@ -266,7 +244,7 @@ int launch_ew(sd_ctx *ctx, double *w, const double *v, const double *u, int64_t 
   unsigned nb = grid_for(items);
   if (slot >= 0) {
     if (nb > RED_BLOCKS) nb = RED_BLOCKS;
-    int rc = ensure_partials(ctx, 2 * RED_BLOCKS); if (rc) return rc;
+    int rc = sd_ensure_partials(ctx, 2 * RED_BLOCKS); if (rc) return rc;
     if (vec) hipLaunchKernelGGL((k_ew2<OP, true>), dim3(nb), dim3(BS), 0, ctx->stream, (double2 *)w, (const double2 *)v, (const double2 *)u, items, a, b, ctx->d_partials);
     else hipLaunchKernelGGL((k_ew<OP, true>), dim3(nb), dim3(BS), 0, ctx->stream, w, v, u, items, a, b, ctx->d_partials);
     hipLaunchKernelGGL(k_reduce_to, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_partials, (int)nb, ctx->d_scalars + slot);
@@ -298,7 +276,7 @@ int sd_k_sub2_nrm(sd_ctx *ctx, double *w, const double *v, const double *u, int6
 }
 int sd_k_krylov_update_nrm(sd_ctx *ctx, double *w, const double *v, const double *u, int64_t N, double ar, double ai,
                            double b, int slot) {
-  int rc = ensure_partials(ctx, 2 * RED_BLOCKS); if (rc) return rc;
+  int rc = sd_ensure_partials(ctx, 2 * RED_BLOCKS); if (rc) return rc;
   unsigned nb = grid_for(N);
   if (nb > RED_BLOCKS) nb = RED_BLOCKS;
   hipLaunchKernelGGL(k_krylov_update, dim3(nb), dim3(BS), 0, ctx->stream, (double2 *)w, (const double2 *)v, (const double2 *)u, N,

@@ -185,6 +185,9 @@ int sd_k_gemv_cols(sd_ctx *ctx, double *y, const double *V, int64_t N, int ncols
 int sd_k_fill_randn(sd_ctx *ctx, double *x, int64_t n, uint64_t seed, uint64_t first);
 double sd_randn_host(uint64_t seed, uint64_t k);
 
+// grows ctx->d_partials to at least `doubles` entries (scratch for per-workgroup partial sums)
+int sd_ensure_partials(sd_ctx *ctx, size_t doubles);
+
 // error helpers
 int sd_set_err(sd_ctx *ctx, int code, const std::string &msg);
 #define SD_HIP(ctx, call)                                                                       \
