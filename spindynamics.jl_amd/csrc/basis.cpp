@@ -239,10 +239,12 @@ int sd_build_plan(sd_model *m, int rank, int nranks, std::string &err) {
       // deal whole orbits to the 8 XCD queues, then interleave the queues (position j of queue x -> block 8j + x)
       std::vector<std::vector<size_t>> q(8);
       size_t o = 0;
+      size_t OC = 1;   // consecutive orbits handed to the same XCD
+      if (const char *e = getenv("SD_XCD_ORBIT_RUN")) OC = (size_t)std::max(1, atoi(e));
       for (size_t k = 0; k < nt;) {
         size_t e = k;
         while (e < nt && (key[idx[e]] >> 8) == (key[idx[k]] >> 8)) ++e;
-        for (size_t t = k; t < e; ++t) q[o % 8].push_back(idx[t]);
+        for (size_t t = k; t < e; ++t) q[(o / OC) % 8].push_back(idx[t]);
         ++o; k = e;
       }
       std::vector<uint32_t> tp; std::vector<int64_t> tb;
