@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: H|psi> matvecs/s for XXZChain(L=32, nup=16) (ComplexF64, N = 601 080 390)
-on N MI355X GPUs of one node, the state sharded by basis-index range for N > 1.
+on N MI355X GPUs of one node, the state sharded over the ranks for N > 1 (popcount-cell ownership by default,
+SD_SHARD_MODE=range for contiguous basis-index ranges).
 
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -163,8 +164,8 @@ def main():
             "dtype": args.dtype,
             "data": "synthetic: counter-based N(0,1) psi keyed by (seed=%d, global index), normalised" % SEED,
             "config": {"workload": "XXZChain(L=%d, nup=%d) open, Jxy=Jz=1, hz=0: out <- H psi, ComplexF64, N=%d; "
-                                   "basis-index-range shards, %d rank(s), halo exchange per step" % (L, nup, N, world),
-                       "rows_per_rank": op.n_local, "halo_rows_rank0": op.n_halo,
+                                   "%s shards, %d rank(s), halo exchange per step" % (L, nup, N, "popcount-cell" if op.mode == "class" else "basis-index-range", world),
+                       "rows_per_rank": op.n_local, "halo_rows_rank0": op.n_halo, "shard_mode": op.mode,
                        "device_path": model.device_path},
             "achieved_hbm_GBs_per_gpu": achieved,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -221,6 +221,11 @@ typedef struct sd_shard_info {
   int64_t row_lo, row_hi;   /* owned global rows */
   int64_t n_local, n_halo;  /* elements */
   int64_t n_recv_slabs, n_send_slabs;
+  int mode;                 /* 0 index ranges (send slabs are slices of psi), 1 popcount cells (send slabs are slices
+                               of the packed send buffer filled by sd_shard_pack_dev) */
+  int64_t n_send;           /* elements of the packed send buffer (mode 1), else 0 */
+  int64_t n_local_tiles;
+  int64_t n_pack;           /* entries of the pack list (mode 1) */
 } sd_shard_info;
 typedef struct sd_slab {
   int peer;                 /* rank on the other side */
@@ -231,6 +236,17 @@ typedef struct sd_slab {
 /* Re-plans the model as shard `rank` of `nranks` (nranks == 1 restores the
  * unsharded plan).  Must be called before any apply on that model. */
 int sd_model_set_shard(sd_model *m, int rank, int nranks);
+/* mode: -1 auto (env SD_SHARD_MODE=range|class, default class when the model allows it), 0 index ranges, 1 popcount cells */
+int sd_model_set_shard_mode(sd_model *m, int rank, int nranks, int mode);
+/* local tiles in natural order: offset in the local vector, GLOBAL basis index of the first row, rows (arrays of
+ * sd_shard_info.n_local_tiles entries; any may be NULL).  local row = local_base + i  <->  global row = global_base + i */
+int sd_model_local_tiles(const sd_model *m, int64_t *local_base, int64_t *global_base, int32_t *len);
+/* mode 1: the pack list -- tile k of it is psi[src[k] .. src[k]+len[k]) -> sendbuf[dst[k] ..) (n_pack entries each) */
+int sd_model_shard_pack_list(const sd_model *m, int64_t *src, int64_t *dst, int32_t *len);
+/* mode 1: gather the tiles the peers need into the contiguous send buffer (n_send elements) */
+int sd_shard_pack_dev(sd_ctx *ctx, const sd_model *m, int dtype, const void *psi_dev, void *sendbuf_dev);
+/* counter-based N(0,1) keyed by the GLOBAL element index into this shard's local vector (any sharding gives the same state) */
+int sd_fill_randn_local_dev(sd_ctx *ctx, const sd_model *m, int dtype, void *x_dev, uint64_t seed);
 /* Sharded apply with the imported partner tiles in a SEPARATE halo buffer (n_halo elements, filled by the exchange):
  * vectors then hold exactly n_local elements and one halo buffer serves every vector of a recursion.
  * epilogue: 0 out = H psi; 1 out = (H psi - b psi)/a; 2 fused Chebyshev term (ComplexF64; phi_prev, psi_t as in

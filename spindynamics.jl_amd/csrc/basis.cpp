@@ -95,10 +95,11 @@ static int64_t tile_base_global(const sd_model *m, uint32_t P) {
 struct TileRef { int64_t base; uint32_t P; };
 
 // marks in need[] every tile (by prefix) that the rows of tiles [k_lo,k_hi) read through a hop
-static void collect_needs(const sd_model *m, const std::vector<TileRef> &tiles, size_t k_lo, size_t k_hi,
+static void collect_needs(const sd_model *m, const std::vector<TileRef> &tiles, const std::vector<int> &owner, int q,
                           int nn_hops, std::vector<uint8_t> &need) {
   const int p = m->p;
-  for (size_t k = k_lo; k < k_hi; ++k) {
+  for (size_t k = 0; k < tiles.size(); ++k) {
+    if (owner[k] != q) continue;
     uint32_t P = tiles[k].P;
     if (nn_hops > 0) {
       for (int b = 1; b <= p - 1; ++b)
@@ -176,32 +177,92 @@ int sd_build_plan(sd_model *m, int rank, int nranks, std::string &err) {
   const size_t T = tiles.size();
   if (T == 0) { err = "empty basis"; return SD_EINTERNAL; }
 
-  // shard boundaries (tile aligned)
-  std::vector<size_t> kb(nranks + 1, 0);
-  for (int r = 1; r < nranks; ++r) {
-    int64_t target = (int64_t)((__int128)m->N * r / nranks);
-    size_t k = std::lower_bound(tiles.begin(), tiles.end(), target,
-                                [](const TileRef &a, int64_t v) { return a.base < v; }) - tiles.begin();
-    kb[r] = std::max(k, kb[r - 1]);
+  // ---- ownership of every tile ----
+  // mode 0 ("range"): contiguous, tile-aligned basis-index ranges (what BASELINE.json's north star names).
+  // mode 1 ("class"): a tile belongs to the cell (k1, k2) = (#up among sites 1..m1, #up among sites 1..m2), m2 < m1 < p,
+  //   and the cells, taken in lexicographic order, are cut into nranks runs of equal weight.  Only the two bonds
+  //   (m1,m1+1) and (m2,m2+1) can move a configuration to another cell, and only across a cut, so a rank imports 3-4x
+  //   fewer rows than with index ranges (L=32: 0.15 / 0.50 / 0.74 imported rows per owned row at 2 / 4 / 8 ranks instead
+  //   of 0.52 / 1.50 / 2.50).  Ownership is then a union of tiles, stored compactly in natural order.
+  std::vector<int> owner(T, 0);
+  std::vector<int64_t> tlen(T);
+  for (size_t k = 0; k < T; ++k) tlen[k] = B(m, LS, m->nup - __builtin_popcount(tiles[k].P));
+  int mode = m->shard_mode_req;
+  if (mode < 0) {
+    mode = 1;
+    if (const char *e = getenv("SD_SHARD_MODE")) mode = (e[0] == 'r') ? 0 : 1;
   }
-  kb[nranks] = T;
-  auto row_of = [&](size_t k) { return k < T ? tiles[k].base : m->N; };
-  auto owner_of = [&](int64_t base) {
-    int r = 0;
-    while (r + 1 < nranks && base >= row_of(kb[r + 1])) ++r;
-    return r;
-  };
-  m->row_lo = row_of(kb[rank]); m->row_hi = row_of(kb[rank + 1]);
-  m->n_local = m->row_hi - m->row_lo;
+  if (nranks == 1 || count_nn_hops(m) == 0 || p < 6) mode = 0;
+  if (mode == 1) {
+    // choose (m1, m2) and the cuts: smallest worst-rank import ratio among balanced cuts (weights from binomials)
+    double best = 1e300; int bm1 = -1, bm2 = -1; std::vector<int> bassign;
+    for (int m1 = 4; m1 <= p - 1; ++m1)
+      for (int m2 = 2; m2 <= m1 - 2; ++m2) {
+        const int W2 = m2 + 1;
+        std::vector<double> w((size_t)(m1 + 1) * W2, 0.0);
+        double tot = 0;
+        for (int k1 = 0; k1 <= m1; ++k1)
+          for (int k2 = 0; k2 <= std::min(k1, m2); ++k2) {
+            const double x = (double)B(m, m2, k2) * (double)B(m, m1 - m2, k1 - k2) * (double)B(m, L - m1, m->nup - k1);
+            w[(size_t)k1 * W2 + k2] = x; tot += x;
+          }
+        std::vector<int> assign((size_t)(m1 + 1) * W2, -1);
+        std::vector<double> size(nranks, 0.0), vol(nranks, 0.0);
+        double acc = 0; int r = 0;
+        for (size_t c = 0; c < w.size(); ++c) {
+          if (w[c] == 0) continue;
+          if (acc + w[c] / 2 > (r + 1) * tot / nranks && r < nranks - 1) ++r;
+          assign[c] = r; acc += w[c]; size[r] += w[c];
+        }
+        bool ok = true;
+        for (int q = 0; q < nranks; ++q) if (size[q] == 0 || size[q] > 1.15 * tot / nranks) ok = false;
+        if (!ok) continue;
+        auto A = [&](int k1, int k2) { return (k1 < 0 || k1 > m1 || k2 < 0 || k2 > m2 || k2 > k1) ? -1 : assign[(size_t)k1 * W2 + k2]; };
+        for (int k1 = 0; k1 <= m1; ++k1)
+          for (int k2 = 0; k2 <= std::min(k1, m2); ++k2) {
+            const int rr = A(k1, k2);
+            if (rr < 0) continue;
+            const double rest = (double)B(m, L - m1, m->nup - k1);
+            auto add = [&](double n, int other) { if (n > 0 && other >= 0 && other != rr) vol[rr] += n; };
+            add((double)B(m, m2 - 1, k2 - 1) * (double)B(m, m1 - m2 - 1, k1 - k2) * rest, A(k1, k2 - 1));
+            add((double)B(m, m2 - 1, k2) * (double)B(m, m1 - m2 - 1, k1 - k2 - 1) * rest, A(k1, k2 + 1));
+            add((double)B(m, m2, k2) * (double)B(m, m1 - m2 - 1, k1 - k2 - 1) * (double)B(m, L - m1 - 1, m->nup - k1), A(k1 - 1, k2));
+            add((double)B(m, m2, k2) * (double)B(m, m1 - m2 - 1, k1 - k2) * (double)B(m, L - m1 - 1, m->nup - k1 - 1), A(k1 + 1, k2));
+          }
+        double score = 0;
+        for (int q = 0; q < nranks; ++q) score = std::max(score, vol[q] / size[q]);
+        if (score < best) { best = score; bm1 = m1; bm2 = m2; bassign = assign; }
+      }
+    if (bm1 < 0) mode = 0;
+    else {
+      const uint32_t mA = (1u << bm1) - 1, mB = (1u << bm2) - 1;
+      for (size_t k = 0; k < T; ++k)
+        owner[k] = bassign[(size_t)__builtin_popcount(tiles[k].P & mA) * (bm2 + 1) + __builtin_popcount(tiles[k].P & mB)];
+    }
+  }
+  if (mode == 0) {
+    for (int r = 1; r < nranks; ++r) {
+      const int64_t target = (int64_t)((__int128)m->N * r / nranks);
+      for (size_t k = 0; k < T; ++k) if (tiles[k].base >= target) owner[k] = std::max(owner[k], r);
+    }
+  }
+  m->shard_mode = mode;
 
+  std::vector<int64_t> local_of(T, -1);
   m->addr.assign(nP, -1);
-  for (size_t k = kb[rank]; k < kb[rank + 1]; ++k) {
+  m->row_lo = -1; m->row_hi = 0; m->n_local = 0;
+  for (size_t k = 0; k < T; ++k) {
+    if (owner[k] != rank) continue;
+    if (m->row_lo < 0) m->row_lo = tiles[k].base;
+    m->row_hi = tiles[k].base + tlen[k];
+    local_of[k] = m->n_local;
     m->tile_prefix.push_back(tiles[k].P);
-    m->tile_base.push_back(tiles[k].base - m->row_lo);
-    m->addr[tiles[k].P] = tiles[k].base - m->row_lo;
-    int t2 = m->nup - __builtin_popcount(tiles[k].P);
-    m->max_tile_len = std::max<int>(m->max_tile_len, (int)B(m, LS, t2));
+    m->tile_base.push_back(m->n_local);
+    m->addr[tiles[k].P] = m->n_local;
+    m->n_local += tlen[k];
+    m->max_tile_len = std::max<int>(m->max_tile_len, (int)tlen[k]);
   }
+  if (m->row_lo < 0) m->row_lo = 0;
 
   // XCD-aware processing order.  Workgroups are dealt round-robin over the 8 XCDs (block b -> XCD b % 8), each with
   // a private 4 MiB L2.  A far bond maps tile P onto tile P' = P ^ bond and both read each other.  Tiles related by
@@ -301,46 +362,64 @@ int sd_build_plan(sd_model *m, int rank, int nranks, std::string &err) {
     }
   }
 
+  m->pack_src.clear(); m->pack_dst.clear(); m->pack_len.clear(); m->n_send = 0;
   if (nranks > 1) {
     const int nn = count_nn_hops(m);
     std::vector<uint8_t> need(nP);
+    std::vector<int64_t> nloc(nranks, 0);
+    for (size_t k = 0; k < T; ++k) nloc[owner[k]] += tlen[k];
     for (int q = 0; q < nranks; ++q) {
       std::fill(need.begin(), need.end(), 0);
-      collect_needs(m, tiles, kb[q], kb[q + 1], nn, need);
-      // walk all tiles in global order; tiles needed by q and owned by someone else form q's halo
-      int64_t halo_off = row_of(kb[q + 1]) - row_of(kb[q]);  // q's n_local
-      sd_slab cur{-1, 0, 0, 0};
-      int64_t cur_end_global = -1;
-      auto flush = [&]() {
-        if (cur.count == 0) return;
-        if (q == rank) m->recv_slabs.push_back(cur);
-        cur.count = 0;
-      };
-      for (size_t k = 0; k < T; ++k) {
-        if (!need[tiles[k].P]) continue;
-        if (k >= kb[q] && k < kb[q + 1]) continue;  // q owns it
-        int own = owner_of(tiles[k].base);
-        int t2 = m->nup - __builtin_popcount(tiles[k].P);
-        int64_t len = B(m, LS, t2);
-        if (q == rank) {
-          m->addr[tiles[k].P] = halo_off;
-          if (cur.count > 0 && cur.peer == own && cur_end_global == tiles[k].base) cur.count += len;
-          else { flush(); cur = {own, halo_off, len, tiles[k].base}; }
-          cur_end_global = tiles[k].base + len;
-        } else if (own == rank) {
-          // q needs one of my tiles: a send slab (merged exactly like q merges its receives)
-          int64_t loc = tiles[k].base - m->row_lo;
-          if (!m->send_slabs.empty() && m->send_slabs.back().peer == q &&
-              m->send_slabs.back().local_offset + m->send_slabs.back().count == loc)
-            m->send_slabs.back().count += len;
-          else m->send_slabs.push_back({q, loc, len, tiles[k].base});
+      collect_needs(m, tiles, owner, q, nn, need);
+      int64_t halo_off = nloc[q];
+      if (mode == 0) {
+        // index ranges: owned rows are globally contiguous, so what travels is a few contiguous slabs of psi itself
+        sd_slab cur{-1, 0, 0, 0};
+        int64_t cur_end_global = -1;
+        auto flush = [&]() { if (cur.count && q == rank) m->recv_slabs.push_back(cur); cur.count = 0; };
+        for (size_t k = 0; k < T; ++k) {
+          if (!need[tiles[k].P] || owner[k] == q) continue;
+          const int own = owner[k];
+          const int64_t len = tlen[k];
+          if (q == rank) {
+            m->addr[tiles[k].P] = halo_off;
+            if (cur.count > 0 && cur.peer == own && cur_end_global == tiles[k].base) cur.count += len;
+            else { flush(); cur = {own, halo_off, len, tiles[k].base}; }
+            cur_end_global = tiles[k].base + len;
+          } else if (own == rank) {
+            const int64_t loc = local_of[k];
+            if (!m->send_slabs.empty() && m->send_slabs.back().peer == q &&
+                m->send_slabs.back().local_offset + m->send_slabs.back().count == loc)
+              m->send_slabs.back().count += len;
+            else m->send_slabs.push_back({q, loc, len, tiles[k].base});
+          }
+          halo_off += len;
         }
-        halo_off += len;
+        flush();
+      } else {
+        // cells: the tiles a peer needs are scattered over the owner's rows, so the owner packs them (natural order) into
+        // a send buffer and exactly one message travels per (owner, receiver) pair
+        for (int o = 0; o < nranks; ++o) {
+          if (o == q) continue;
+          const int64_t start = halo_off, sstart = m->n_send;
+          int64_t count = 0;
+          for (size_t k = 0; k < T; ++k) {
+            if (owner[k] != o || !need[tiles[k].P]) continue;
+            if (q == rank) m->addr[tiles[k].P] = halo_off;
+            if (o == rank) { m->pack_src.push_back(local_of[k]); m->pack_dst.push_back(m->n_send); m->pack_len.push_back((int32_t)tlen[k]); m->n_send += tlen[k]; }
+            halo_off += tlen[k]; count += tlen[k];
+          }
+          if (count > 0) {
+            if (q == rank) m->recv_slabs.push_back({o, start, count, -1});
+            if (o == rank) m->send_slabs.push_back({q, sstart, count, -1});
+          }
+        }
       }
-      flush();
       if (q == rank) m->n_halo = halo_off - m->n_local;
     }
   }
+  m->tile_gbase.resize(m->tile_prefix.size());
+  for (size_t k = 0; k < m->tile_prefix.size(); ++k) m->tile_gbase[k] = tile_base_global(m, m->tile_prefix[k]);
   return SD_OK;
 }
 
@@ -425,6 +504,11 @@ int sd_upload_model(sd_model *m, std::string &err) {
     if ((rc = up(m, m->suf_states, &d.suf_states, err))) return rc;
     if ((rc = up(m, m->suf_off, &d.suf_off, err))) return rc;
     if ((rc = up(m, m->suf_rank, &d.suf_rank, err))) return rc;
+    if ((rc = up(m, m->tile_gbase, &d.tile_gbase, err))) return rc;
+    d.n_pack = (int)m->pack_len.size();
+    if ((rc = up(m, m->pack_src, &d.pack_src, err))) return rc;
+    if ((rc = up(m, m->pack_dst, &d.pack_dst, err))) return rc;
+    if ((rc = up(m, m->pack_len, &d.pack_len, err))) return rc;
     d.n_groups = (int)m->group_P0.size();
     d.n_singles = (int)m->single_prefix.size();
     m->single_rec.resize(m->single_prefix.size());

@@ -200,6 +200,12 @@ int sd_model_rank(const sd_model *m, const uint64_t *states, int64_t n, int64_t 
   return SD_OK;
 }
 
+int sd_model_set_shard_mode(sd_model *m, int rank, int nranks, int mode) {
+  if (!m || mode < -1 || mode > 1) return SD_EARG;
+  m->shard_mode_req = mode;
+  return sd_model_set_shard(m, rank, nranks);
+}
+
 int sd_model_set_shard(sd_model *m, int rank, int nranks) {
   if (!m) return SD_EARG;
   std::string err;
@@ -218,6 +224,8 @@ int sd_model_shard_info(const sd_model *m, sd_shard_info *out) {
   out->row_lo = m->row_lo; out->row_hi = m->row_hi;
   out->n_local = m->n_local; out->n_halo = m->n_halo;
   out->n_recv_slabs = (int64_t)m->recv_slabs.size(); out->n_send_slabs = (int64_t)m->send_slabs.size();
+  out->mode = m->shard_mode; out->n_send = m->n_send; out->n_local_tiles = (int64_t)m->tile_prefix.size();
+  out->n_pack = (int64_t)m->pack_len.size();
   return SD_OK;
 }
 
@@ -226,6 +234,41 @@ int sd_model_shard_slabs(const sd_model *m, sd_slab *recv_out, sd_slab *send_out
   if (recv_out) for (size_t i = 0; i < m->recv_slabs.size(); ++i) recv_out[i] = m->recv_slabs[i];
   if (send_out) for (size_t i = 0; i < m->send_slabs.size(); ++i) send_out[i] = m->send_slabs[i];
   return SD_OK;
+}
+
+int sd_model_local_tiles(const sd_model *m, int64_t *local_base, int64_t *global_base, int32_t *len) {
+  if (!m || m->p < 0) return SD_EARG;
+  for (size_t k = 0; k < m->tile_prefix.size(); ++k) {
+    if (local_base) local_base[k] = m->tile_base[k];
+    if (global_base) global_base[k] = m->tile_gbase.size() == m->tile_prefix.size() ? m->tile_gbase[k] : -1;
+    if (len) len[k] = (int32_t)sd_binom(m->LS, m->nup - __builtin_popcount(m->tile_prefix[k]));
+  }
+  return SD_OK;
+}
+
+int sd_model_shard_pack_list(const sd_model *m, int64_t *src, int64_t *dst, int32_t *len) {
+  if (!m) return SD_EARG;
+  for (size_t k = 0; k < m->pack_len.size(); ++k) {
+    if (src) src[k] = m->pack_src[k];
+    if (dst) dst[k] = m->pack_dst[k];
+    if (len) len[k] = m->pack_len[k];
+  }
+  return SD_OK;
+}
+
+int sd_shard_pack_dev(sd_ctx *ctx, const sd_model *m, int dtype, const void *psi_dev, void *sendbuf_dev) {
+  if (!ctx) return SD_EARG;
+  if (!m || !psi_dev) return sd_set_err(ctx, SD_EARG, "null argument");
+  if (dtype != SD_F64 && dtype != SD_C128) return sd_set_err(ctx, SD_EARG, "bad dtype");
+  if (m->n_send > 0 && !sendbuf_dev) return sd_set_err(ctx, SD_EARG, "this shard needs a send buffer");
+  return sd_launch_pack(ctx, m, dtype, psi_dev, sendbuf_dev);
+}
+
+int sd_fill_randn_local_dev(sd_ctx *ctx, const sd_model *m, int dtype, void *x_dev, uint64_t seed) {
+  if (!ctx) return SD_EARG;
+  if (!m || !x_dev) return sd_set_err(ctx, SD_EARG, "null argument");
+  if (dtype != SD_F64 && dtype != SD_C128) return sd_set_err(ctx, SD_EARG, "bad dtype");
+  return sd_launch_fill_randn_local(ctx, m, dtype, x_dev, seed);
 }
 
 // ---- operator level ----

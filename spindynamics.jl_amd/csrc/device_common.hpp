@@ -218,4 +218,18 @@ __device__ __forceinline__ void buf_load(double2 &v, __amdgpu_buffer_rsrc_t r, u
 }
 
 
+// counter-based N(0,1): element k of stream `seed` = Box-Muller on two uniforms hashed from (seed, k)
+__host__ __device__ inline uint64_t sd_mix64(uint64_t z) {
+  z += 0x9E3779B97F4A7C15ULL;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  return z ^ (z >> 31);
+}
+__host__ __device__ inline double sd_randn_at(uint64_t seed, uint64_t k) {
+  const uint64_t h1 = sd_mix64(seed ^ sd_mix64(2 * k)), h2 = sd_mix64(seed ^ sd_mix64(2 * k + 1));
+  const double u1 = ((double)(h1 >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+  const double u2 = ((double)(h2 >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+  return sqrt(-2.0 * log(u1)) * cos(6.283185307179586476925286766559 * u2);
+}
+
 }  // namespace sd_dev

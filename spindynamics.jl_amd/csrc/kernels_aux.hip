@@ -137,6 +137,28 @@ __global__ __launch_bounds__(256) void k_obs_reduce(const double *__restrict__ p
 }
 
 
+
+// ---- sharded plans: pack the tiles peers need into the contiguous send buffer; fill a local vector by GLOBAL index ----
+template <int NC>
+__global__ __launch_bounds__(256) void k_pack(sd_dev_model dm, const double *__restrict__ psi_, double *__restrict__ send_) {
+  using V = typename VT<NC>::type;
+  const V *__restrict__ psi = reinterpret_cast<const V *>(psi_);
+  V *__restrict__ send = reinterpret_cast<V *>(send_);
+  for (int t = blockIdx.x; t < dm.n_pack; t += gridDim.x) {
+    const int64_t src = dm.pack_src[t], dst = dm.pack_dst[t];
+    const int len = dm.pack_len[t];
+    for (int i = threadIdx.x; i < len; i += blockDim.x) send[dst + i] = psi[src + i];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_fill_randn_tiles(sd_dev_model dm, double *__restrict__ x, int per, uint64_t seed) {
+  for (int t = blockIdx.x; t < dm.n_tiles; t += gridDim.x) {
+    const int64_t lb = dm.tile_base[t], gb = dm.tile_gbase[t];
+    const int len = (int)binom_g(dm, dm.LS, dm.nup - __popc(dm.tile_prefix[t]));
+    for (int i = threadIdx.x; i < len * per; i += blockDim.x)
+      x[lb * per + i] = sd_randn_at(seed, (uint64_t)(gb * per + i));
+  }
+}
 }  // namespace
 
 // mode 0: out[L] = magnetization per site; mode 1: out[L] = lag sums R_r.  psi is a device vector.
@@ -164,6 +186,28 @@ int sd_launch_observable(sd_ctx *ctx, const sd_model *m, int dtype, const void *
     if (rc) return rc;
     for (int k = 0; k < cn; ++k) out_host[c0 + k] = tmp[k];
   }
+  return SD_OK;
+}
+
+int sd_launch_pack(sd_ctx *ctx, const sd_model *m, int dtype, const void *psi, void *sendbuf) {
+  if (!m->dev_ready) return sd_set_err(ctx, SD_EARG, "model has no device tables (created without a context)");
+  const sd_dev_model &dm = m->dm;
+  if (dm.n_pack == 0) return SD_OK;
+  const int nb = std::min(dm.n_pack, 8192);
+  if (dtype == SD_C128) hipLaunchKernelGGL(k_pack<2>, dim3(nb), dim3(256), 0, ctx->stream, dm, (const double *)psi, (double *)sendbuf);
+  else hipLaunchKernelGGL(k_pack<1>, dim3(nb), dim3(256), 0, ctx->stream, dm, (const double *)psi, (double *)sendbuf);
+  SD_HIP(ctx, hipGetLastError());
+  return SD_OK;
+}
+
+int sd_launch_fill_randn_local(sd_ctx *ctx, const sd_model *m, int dtype, void *x, uint64_t seed) {
+  if (!m->dev_ready) return sd_set_err(ctx, SD_EARG, "model has no device tables (created without a context)");
+  const sd_dev_model &dm = m->dm;
+  const int per = dtype == SD_C128 ? 2 : 1;
+  if (m->p < 0) return sd_k_fill_randn(ctx, (double *)x, dm.N * per, seed, 0);
+  if (dm.n_tiles == 0) return SD_OK;
+  hipLaunchKernelGGL(k_fill_randn_tiles, dim3(std::min(dm.n_tiles, 8192)), dim3(256), 0, ctx->stream, dm, (double *)x, per, seed);
+  SD_HIP(ctx, hipGetLastError());
   return SD_OK;
 }
 

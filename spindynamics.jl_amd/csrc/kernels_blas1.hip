@@ -179,22 +179,9 @@ __global__ __launch_bounds__(BS) void k_gemv_cols(double *__restrict__ y, const 
   }
 }
 
-// counter-based N(0,1): element k of stream `seed` = Box-Muller on two uniforms hashed from (seed, k)
-__host__ __device__ inline uint64_t mix64(uint64_t z) {
-  z += 0x9E3779B97F4A7C15ULL;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
-  return z ^ (z >> 31);
-}
-__host__ __device__ inline double randn_at(uint64_t seed, uint64_t k) {
-  const uint64_t h1 = mix64(seed ^ mix64(2 * k)), h2 = mix64(seed ^ mix64(2 * k + 1));
-  const double u1 = ((double)(h1 >> 11) + 0.5) * (1.0 / 9007199254740992.0);
-  const double u2 = ((double)(h2 >> 11) + 0.5) * (1.0 / 9007199254740992.0);
-  return sqrt(-2.0 * log(u1)) * cos(6.283185307179586476925286766559 * u2);
-}
 __global__ __launch_bounds__(BS) void k_fill_randn(double *__restrict__ x, int64_t n, uint64_t seed, uint64_t first) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) x[i] = randn_at(seed, first + (uint64_t)i);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) x[i] = sd_dev::sd_randn_at(seed, first + (uint64_t)i);
 }
 
 inline unsigned grid_for(int64_t n) {
@@ -206,7 +193,7 @@ inline unsigned grid_for(int64_t n) {
 
 }  // namespace
 
-double sd_randn_host(uint64_t seed, uint64_t k) { return randn_at(seed, k); }
+double sd_randn_host(uint64_t seed, uint64_t k) { return sd_dev::sd_randn_at(seed, k); }
 
 int sd_k_dot(sd_ctx *ctx, int nc, const double *x, const double *y, int64_t N, int slot) {
   int rc = sd_ensure_partials(ctx, 2 * RED_BLOCKS); if (rc) return rc;

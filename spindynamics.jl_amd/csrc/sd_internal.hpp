@@ -77,6 +77,10 @@ struct sd_dev_model {
   int n_tiles;
   const uint32_t *tile_prefix;   // per local tile (processing order)
   const int64_t *tile_base;      // per local tile: offset of its first row in the local vector
+  const int64_t *tile_gbase;     // per local tile: GLOBAL basis index of its first row
+  int n_pack;                    // cell-sharded plans: tiles this rank packs into its send buffer
+  const int64_t *pack_src, *pack_dst;
+  const int32_t *pack_len;
   const int64_t *addr;           // 2^p entries: offset of tile P in [local | halo], -1 if unavailable
   const uint16_t *suf_states;    // concatenated sectors (LS, t'), t' = 0..LS
   const int32_t *suf_off;        // LS+2 offsets into suf_states
@@ -108,6 +112,11 @@ struct sd_model {
   std::vector<uint16_t> suf_states, suf_rank;
   std::vector<int32_t> suf_off;
   std::vector<sd_slab> recv_slabs, send_slabs;
+  int shard_mode_req = -1;       // -1 auto (env SD_SHARD_MODE), 0 index ranges, 1 popcount cells
+  int shard_mode = 0;           // mode in effect
+  int64_t n_send = 0;           // elements of the packed send buffer (cell mode)
+  std::vector<int64_t> pack_src, pack_dst, tile_gbase;
+  std::vector<int32_t> pack_len;
   std::vector<uint32_t> group_P0, group_gens;  // grouped tiles (unsharded NN-chain plans only)
   std::vector<uint32_t> single_prefix;
   int group_ngen = 0;          // generator bonds per group (2 or 3)
@@ -153,6 +162,8 @@ struct sd_epi_args {
 int sd_launch_apply(sd_ctx *ctx, const sd_model *m, int dtype, void *out, const void *psi, int epi,
                     const sd_epi_args &ea);
 int sd_launch_observable(sd_ctx *ctx, const sd_model *m, int dtype, const void *psi, int mode, double *out_host);
+int sd_launch_pack(sd_ctx *ctx, const sd_model *m, int dtype, const void *psi, void *sendbuf);
+int sd_launch_fill_randn_local(sd_ctx *ctx, const sd_model *m, int dtype, void *x, uint64_t seed);
 int sd_launch_szq(sd_ctx *ctx, const sd_model *m, int dtype_in, const void *psi0, double q, void *phi);
 
 // BLAS-1 style kernels on device vectors of `n` doubles (n = nc * N).

@@ -1,23 +1,32 @@
-"""Index-range sharding of the Hilbert-space vector over GPUs (one process per GPU).
+"""Sharding of the Hilbert-space vector over GPUs (one process per GPU).
 
-The reference has no distributed layer; this is the new capability BASELINE.json's north star asks for.  Rank r owns the
-contiguous, tile-aligned basis-index range [row_lo, row_hi).  Vectors hold exactly the n_local owned elements.  Before each
-apply the psi values of hop partners that live on other ranks are imported into ONE halo buffer per operator (n_halo
-elements, shared by every vector of a recursion): a grouped send/recv of a few CONTIGUOUS slabs per peer -- a hop on a prefix
-bond maps whole tiles onto whole tiles, so no per-element index lists travel.  torch.distributed P2P ops, i.e. RCCL over xGMI
-on GPUs (backend "nccl") and gloo in the CPU tests.
+The reference has no distributed layer; this is the new capability BASELINE.json's north star asks for.  A rank owns a set
+of whole tiles and its vectors hold exactly the n_local owned elements.  Before each apply the psi values of hop partners
+that live on other ranks are imported into ONE halo buffer per operator (n_halo elements, shared by every vector of a
+recursion).  A hop on a prefix bond maps whole tiles onto whole tiles, so whole tiles travel, never per-element index lists.
+
+Two ownership modes (csrc/basis.cpp):
+  "range": contiguous basis-index ranges; a few contiguous slabs of psi itself are sent per peer.
+  "class" (default): popcount cells (k1, k2) of two nested site blocks cut into equal-weight runs; only two bonds can cross a
+      cut, so 3-4x fewer rows are imported (L=32: 0.15 / 0.50 / 0.74 per owned row at 2 / 4 / 8 ranks instead of 0.52 / 1.50 /
+      2.50); the owner packs the requested tiles into a send buffer and ONE message travels per (owner, receiver) pair.
+Transport: torch.distributed P2P ops, i.e. RCCL over xGMI on GPUs (backend "nccl") and gloo in the CPU tests.
 """
 from . import _lib
 from ._lib import check, lib
 
 
 class ShardedOperator:
-    def __init__(self, model, rank, world, exchange_fn=None):
+    def __init__(self, model, rank, world, exchange_fn=None, mode=None, pack_fn=None):
         self.model = model
         self.rank, self.world = rank, world
         self._exchange_fn = exchange_fn   # tests inject an emulated exchange for virtual shards in one process
-        model.set_shard(rank, world)
+        self._pack_fn = pack_fn           # CPU tests inject a numpy pack (the product packs with a HIP kernel)
+        model.set_shard(rank, world, mode)
         info = model.shard_info()
+        self.mode = "class" if int(info.mode) == 1 else "range"
+        self.n_send = int(info.n_send)
+        self._send = {}
         self.n_local, self.n_halo = int(info.n_local), int(info.n_halo)
         self.row_lo, self.row_hi = int(info.row_lo), int(info.row_hi)
         self.recv_slabs, self.send_slabs = model.shard_slabs()
@@ -37,6 +46,28 @@ class ShardedOperator:
             self._halo[key] = torch.empty(max(self.n_halo, 1), dtype=like.dtype, device=like.device)
         return self._halo[key]
 
+    def sendbuf(self, like):
+        import torch
+        key = (like.dtype, str(like.device))
+        if key not in self._send:
+            self._send[key] = torch.empty(max(self.n_send, 1), dtype=like.dtype, device=like.device)
+        return self._send[key]
+
+    def pack(self, psi):
+        """class mode: gather the tiles the peers asked for into the contiguous send buffer."""
+        buf = self.sendbuf(psi)
+        if self.n_send == 0:
+            return buf
+        if self._pack_fn is not None:
+            self._pack_fn(self, psi, buf)
+            return buf
+        import torch
+        m = self.model
+        m.ctx.set_stream(torch.cuda.current_stream(psi.device).cuda_stream)
+        code = _lib.SD_C128 if psi.is_complex() else _lib.SD_F64
+        check(lib().sd_shard_pack_dev(m.ctx.h, m.h, code, psi.data_ptr(), buf.data_ptr()), m.ctx.h)
+        return buf
+
     def halo_bytes(self, itemsize=16):
         return self.n_halo * itemsize
 
@@ -50,7 +81,8 @@ class ShardedOperator:
             return halo
         import torch
         import torch.distributed as dist
-        src = torch.view_as_real(psi) if psi.is_complex() else psi
+        out = self.pack(psi) if self.mode == "class" else psi     # what the send slabs index
+        src = torch.view_as_real(out) if out.is_complex() else out
         dst = torch.view_as_real(halo) if halo.is_complex() else halo
         nl = self.n_local
         ops = []
@@ -119,8 +151,8 @@ class ShardedOperator:
             return x
         m = self.model
         m.ctx.set_stream(torch.cuda.current_stream(x.device).cuda_stream)
-        per = 2 if x.is_complex() else 1
-        check(lib().sd_fill_randn_dev(m.ctx.h, x.data_ptr(), self.n_local * per, int(seed), self.row_lo * per), m.ctx.h)
+        code = _lib.SD_C128 if x.is_complex() else _lib.SD_F64
+        check(lib().sd_fill_randn_local_dev(m.ctx.h, m.h, code, x.data_ptr(), int(seed)), m.ctx.h)
         return x
 
     def norm(self, x, group=None):

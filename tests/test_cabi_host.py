@@ -125,47 +125,89 @@ def test_randn_host_stream(pkg):
     assert abs(x.mean()) < 0.02 and abs(x.std() - 1) < 0.02
 
 
+def imported_rows(models, slabs, r):
+    """Global basis index of every element of rank r's halo buffer, in halo order (both ownership modes)."""
+    info = models[r].shard_info()
+    out = np.full(int(info.n_halo), -1, dtype=np.int64)
+    for (peer, lo, cnt, g) in slabs[r][0]:
+        lo -= int(info.n_local)
+        if int(info.mode) == 0:
+            out[lo:lo + cnt] = np.arange(g, g + cnt)
+        else:   # class mode: the peer packs its tiles in natural order; exactly one message per (peer, r) pair
+            rows = models[peer].local_rows()
+            src, dst, ln = models[peer].pack_list()
+            (soff, scnt), = [(o, c) for (q, o, c, _g) in slabs[peer][1] if q == r]
+            assert scnt == cnt
+            sel = (dst >= soff) & (dst < soff + scnt)
+            packed = np.concatenate([rows[a:a + c] for a, c in zip(src[sel], ln[sel])])
+            out[lo:lo + cnt] = packed
+    return out
+
+
+@pytest.mark.parametrize("mode", ["range", "class"])
 @pytest.mark.parametrize("L,nup,P", [(12, 6, 2), (14, 7, 3), (16, 8, 2), (16, 8, 8), (18, 9, 4), (17, 5, 5)])
-def test_shard_plan_is_consistent(pkg, L, nup, P, monkeypatch):
-    monkeypatch.setenv("SD_SUFFIX_BITS", "8")      # many tiles even at small L
+def test_shard_plan_is_consistent(pkg, L, nup, P, mode, monkeypatch):
+    monkeypatch.setenv("SD_SUFFIX_BITS", "6")      # many tiles even at small L
     models = []
     for r in range(P):
         m = pkg.XXZChain(L, nup=nup, ctx=None)
-        m.set_shard(r, P)
+        m.set_shard(r, P, mode)
         models.append(m)
     infos = [m.shard_info() for m in models]
     N = models[0].N
-    # owned ranges tile [0, N) in rank order
-    assert infos[0].row_lo == 0 and infos[-1].row_hi == N
-    for a, b in zip(infos[:-1], infos[1:]):
-        assert a.row_hi == b.row_lo
+    # the owned rows of all ranks partition [0, N)
+    rows = [m.local_rows() for m in models]
+    assert np.array_equal(np.sort(np.concatenate(rows)), np.arange(N))
+    if mode == "range":
+        assert all(int(i.mode) == 0 for i in infos)
+        assert infos[0].row_lo == 0 and infos[-1].row_hi == N
+        for a, b in zip(infos[:-1], infos[1:]):
+            assert a.row_hi == b.row_lo
+        for r in range(P):
+            assert np.array_equal(rows[r], np.arange(infos[r].row_lo, infos[r].row_hi))
     slabs = [m.shard_slabs() for m in models]
     for r in range(P):
         recv, send = slabs[r]
         off = infos[r].n_local
         for (peer, lo, cnt, g) in recv:             # halo slabs are packed back to back after the owned rows
             assert lo == off and cnt > 0 and peer != r
-            assert infos[peer].row_lo <= g and g + cnt <= infos[peer].row_hi
             off += cnt
         assert off == infos[r].n_local + infos[r].n_halo
-        for (peer, lo, cnt, g) in send:
-            assert 0 <= lo and lo + cnt <= infos[r].n_local and g == infos[r].row_lo + lo
         for q in range(P):                          # what r sends to q is exactly what q receives from r, in order
-            s = [(c, g) for (peer, _, c, g) in send if peer == q]
-            t = [(c, g) for (peer, _, c, g) in slabs[q][0] if peer == r]
-            assert s == t
-    # every hop partner of every owned row is either owned or inside a received slab
+            s_ = [c for (peer, _, c, _g) in send if peer == q]
+            t_ = [c for (peer, _, c, _g) in slabs[q][0] if peer == r]
+            assert s_ == t_
+        if int(infos[r].mode) == 1:
+            assert sum(c for (_, _, c, _g) in send) == infos[r].n_send
+            assert all(len([1 for (peer, _, _, _g) in send if peer == q]) <= 1 for q in range(P))
+    # every hop partner of every owned row is either owned or inside the halo
     full = pkg.XXZChain(L, nup=nup, ctx=None)
     st = full.states
     for r in range(P):
-        lo, hi = infos[r].row_lo, infos[r].row_hi
         have = np.zeros(N, dtype=bool)
-        have[lo:hi] = True
-        for (_, _, cnt, g) in slabs[r][0]:
-            have[g:g + cnt] = True
-        rows = st[lo:hi].astype(np.uint64)
+        have[rows[r]] = True
+        imp = imported_rows(models, slabs, r)
+        assert (imp >= 0).all()
+        have[imp] = True
+        mine = st[rows[r]].astype(np.uint64)
         for i in range(1, L):
-            bi = (rows >> np.uint64(i - 1)) & np.uint64(1)
-            bj = (rows >> np.uint64(i)) & np.uint64(1)
-            fl = rows[bi != bj] ^ np.uint64((1 << (i - 1)) | (1 << i))
+            bi = (mine >> np.uint64(i - 1)) & np.uint64(1)
+            bj = (mine >> np.uint64(i)) & np.uint64(1)
+            fl = mine[bi != bj] ^ np.uint64((1 << (i - 1)) | (1 << i))
             assert have[full.rank(fl)].all()
+
+
+def test_class_mode_cuts_halo_volume(pkg, monkeypatch):
+    """The popcount-cell ownership imports several times fewer rows than index ranges (here L=24, 4 ranks)."""
+    monkeypatch.setenv("SD_SUFFIX_BITS", "8")
+    tot = {}
+    for mode in ("range", "class"):
+        h = 0
+        for r in range(4):
+            m = pkg.XXZChain(24, nup=12, ctx=None)
+            m.set_shard(r, 4, mode)
+            i = m.shard_info()
+            assert int(i.mode) == (1 if mode == "class" else 0)
+            h = max(h, i.n_halo / i.n_local)
+        tot[mode] = h
+    assert tot["class"] < 0.5 * tot["range"]

@@ -7,8 +7,10 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("L,nup,P,ls", [(16, 8, 2, 8), (16, 8, 3, 8), (18, 9, 8, 9), (20, 10, 4, 12), (17, 6, 5, 8), (14, 7, 8, 13)])
-def test_virtual_shards_bit_identical(pkg, L, nup, P, ls, monkeypatch):
+@pytest.mark.parametrize("mode", ["range", "class"])
+@pytest.mark.parametrize("L,nup,P,ls", [(16, 8, 2, 8), (16, 8, 3, 8), (18, 9, 8, 9), (20, 10, 4, 12), (17, 6, 5, 8), (14, 7, 8, 13),
+                                        (20, 10, 8, 8), (22, 11, 4, 10)])
+def test_virtual_shards_bit_identical(pkg, L, nup, P, ls, mode, monkeypatch):
     import torch
     monkeypatch.setenv("SD_SUFFIX_BITS", str(ls))
     full = pkg.XXZChain(L, nup=nup)
@@ -19,10 +21,12 @@ def test_virtual_shards_bit_identical(pkg, L, nup, P, ls, monkeypatch):
     ops, bufs = [], []
     for r in range(P):
         m = pkg.XXZChain(L, nup=nup)
-        op = pkg.ShardedOperator(m, r, P)
-        buf = torch.from_numpy(psi[op.row_lo:op.row_hi].copy()).cuda()
+        op = pkg.ShardedOperator(m, r, P, mode=mode)
+        buf = torch.from_numpy(psi[m.local_rows()].copy()).cuda()
         op.halo(buf).fill_(float("nan"))
         ops.append(op); bufs.append(buf)
+    # class mode: the owner packs the requested tiles with the HIP pack kernel, the send slabs index that buffer
+    outs = [op.pack(b) if op.mode == "class" else b for op, b in zip(ops, bufs)]
     # emulate the grouped send/recv: k-th slab r->q pairs with the k-th slab q receives from r
     for q in range(P):
         hq = ops[q].halo(bufs[q])
@@ -32,12 +36,12 @@ def test_virtual_shards_bit_identical(pkg, L, nup, P, ls, monkeypatch):
             assert len(sends) == len(recvs)
             for (_, so, cnt, _g), (_, ro, cnt2, _g2) in zip(sends, recvs):
                 assert cnt == cnt2
-                hq[ro - ops[q].n_local:ro - ops[q].n_local + cnt] = bufs[r][so:so + cnt]
+                hq[ro - ops[q].n_local:ro - ops[q].n_local + cnt] = outs[r][so:so + cnt]
     got = np.empty_like(psi)
     for r in range(P):
         out = torch.empty_like(bufs[r])
         ops[r].apply(out, bufs[r], exchange=False)
-        got[ops[r].row_lo:ops[r].row_hi] = out.cpu().numpy()
+        got[ops[r].model.local_rows()] = out.cpu().numpy()
     assert np.array_equal(got, want)
     assert sum(o.n_local for o in ops) == full.N
 
@@ -58,3 +62,27 @@ def test_sharded_chebyshev_matches_single_gpu(pkg, O, monkeypatch):
     got = op.chebyshev_time_evolve(torch.from_numpy(psi0).cuda(), 0.3, cheb_n=40, Ebounds=(-8.0, 8.0))
     want = O.chebyshev_time_evolve(r, psi0, 0.3, cheb_n=40, Ebounds=(-8.0, 8.0))
     assert np.abs(got.cpu().numpy() - want).max() <= 1e-14
+
+
+@pytest.mark.parametrize("mode", ["range", "class"])
+def test_sharded_fill_randn_is_sharding_independent(pkg, mode, monkeypatch):
+    """bench.py's synthetic psi is keyed by the GLOBAL element index: every sharding produces the same state."""
+    import torch
+    monkeypatch.setenv("SD_SUFFIX_BITS", "8")
+    L, nup, P = 18, 9, 4
+    full = pkg.XXZChain(L, nup=nup)
+    ref = torch.empty(full.N, dtype=torch.complex128, device="cuda")
+    pkg.ShardedOperator(full, 0, 1).fill_randn(ref, 1234)
+    ref = ref.cpu().numpy()
+    host = np.empty(2 * 64)
+    import ctypes as C
+    pkg.lib().sd_fill_randn_host(host.ctypes.data_as(C.POINTER(C.c_double)), len(host), 1234, 0)
+    assert np.abs(ref[:64].view(np.float64) - host).max() <= 1e-15     # same stream on host and device (libm ulp)
+    got = np.empty_like(ref)
+    for r in range(P):
+        m = pkg.XXZChain(L, nup=nup)
+        op = pkg.ShardedOperator(m, r, P, mode=mode)
+        x = op.empty(torch.complex128, "cuda")
+        op.fill_randn(x, 1234)
+        got[m.local_rows()] = x.cpu().numpy()
+    assert np.array_equal(got, ref)
