@@ -226,6 +226,7 @@ typedef struct sd_shard_info {
   int64_t n_send;           /* elements of the packed send buffer (mode 1), else 0 */
   int64_t n_local_tiles;
   int64_t n_pack;           /* entries of the pack list (mode 1) */
+  int64_t n_interior_tiles; /* tiles whose hop partners are all owned (sd_apply_sharded_dev part 1) */
 } sd_shard_info;
 typedef struct sd_slab {
   int peer;                 /* rank on the other side */
@@ -250,10 +251,11 @@ int sd_fill_randn_local_dev(sd_ctx *ctx, const sd_model *m, int dtype, void *x_d
 /* Sharded apply with the imported partner tiles in a SEPARATE halo buffer (n_halo elements, filled by the exchange):
  * vectors then hold exactly n_local elements and one halo buffer serves every vector of a recursion.
  * epilogue: 0 out = H psi; 1 out = (H psi - b psi)/a; 2 fused Chebyshev term (ComplexF64; phi_prev, psi_t as in
- * sd_cheb_step_dev).  All pointers are device pointers. */
+ * sd_cheb_step_dev).  part: 0 all tiles; 1 only the interior tiles (every hop partner owned: reads no halo, so it
+ * can run while the exchange is in flight); 2 only the boundary tiles.  All pointers are device pointers. */
 int sd_apply_sharded_dev(sd_ctx *ctx, const sd_model *m, int dtype, void *out_dev, const void *psi_dev,
                          const void *halo_dev, int64_t n_local, int epilogue, double a, double b,
-                         double c_re, double c_im, const void *phi_prev_dev, void *psi_t_dev);
+                         double c_re, double c_im, const void *phi_prev_dev, void *psi_t_dev, int part);
 int sd_model_shard_info(const sd_model *m, sd_shard_info *out);
 int sd_model_shard_slabs(const sd_model *m, sd_slab *recv_out, sd_slab *send_out);
 

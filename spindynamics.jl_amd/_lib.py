@@ -38,7 +38,8 @@ class ZeroNormError(RuntimeError):
 class sd_shard_info(C.Structure):
     _fields_ = [("rank", C.c_int), ("nranks", C.c_int), ("row_lo", C.c_int64), ("row_hi", C.c_int64),
                 ("n_local", C.c_int64), ("n_halo", C.c_int64), ("n_recv_slabs", C.c_int64),
-                ("n_send_slabs", C.c_int64), ("mode", C.c_int), ("n_send", C.c_int64), ("n_local_tiles", C.c_int64), ("n_pack", C.c_int64)]
+                ("n_send_slabs", C.c_int64), ("mode", C.c_int), ("n_send", C.c_int64), ("n_local_tiles", C.c_int64), ("n_pack", C.c_int64),
+                ("n_interior_tiles", C.c_int64)]
 
 
 class sd_slab(C.Structure):
@@ -100,7 +101,7 @@ PROTOTYPES = {
     "sd_fill_randn_dev": (_i, [_vp, _vp, _i64, _u64, _u64]),
     "sd_fill_randn_host": (_i, [_dp, _i64, _u64, _u64]),
     "sd_model_set_shard": (_i, [_vp, _i, _i]),
-    "sd_apply_sharded_dev": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i64, _i, _d, _d, _d, _d, _vp, _vp]),
+    "sd_apply_sharded_dev": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i64, _i, _d, _d, _d, _d, _vp, _vp, _i]),
     "sd_model_set_shard_mode": (_i, [_vp, _i, _i, _i]),
     "sd_model_local_tiles": (_i, [_vp, _i64p, _i64p, _ip]),
     "sd_model_shard_pack_list": (_i, [_vp, _i64p, _i64p, _ip]),

@@ -418,6 +418,36 @@ int sd_build_plan(sd_model *m, int rank, int nranks, std::string &err) {
       if (q == rank) m->n_halo = halo_off - m->n_local;
     }
   }
+  // interior tiles (every hop partner owned) first: they can run while the halo exchange is still in flight
+  m->n_interior = (int)m->single_prefix.size();
+  if (nranks > 1 && m->n_halo > 0) {
+    const int nn = count_nn_hops(m);
+    auto remote = [&](uint32_t Q) { return Q < nP && m->addr[Q] >= m->n_local; };
+    std::vector<uint8_t> boundary(m->single_prefix.size(), 0);
+    for (size_t k = 0; k < m->single_prefix.size(); ++k) {
+      const uint32_t P = m->single_prefix[k];
+      bool bd = false;
+      if (nn > 0) {
+        for (int b = 1; b <= p - 1 && !bd; ++b)
+          if ((((P >> (b - 1)) ^ (P >> b)) & 1u) && remote(P ^ (3u << (b - 1)))) bd = true;
+        if (!bd && p >= 1 && remote(P ^ (1u << (p - 1)))) bd = true;
+      }
+      for (size_t h = (size_t)nn; h < m->hop_i.size() && !bd; ++h) {
+        const int i = m->hop_i[h], j = m->hop_j[h];
+        uint32_t Q = P;
+        if (i <= p) Q ^= 1u << (i - 1);
+        if (j <= p) Q ^= 1u << (j - 1);
+        if (Q != P && remote(Q)) bd = true;
+      }
+      boundary[k] = bd;
+    }
+    std::vector<uint32_t> sp; std::vector<int64_t> sb;
+    for (int pass = 0; pass < 2; ++pass)
+      for (size_t k = 0; k < boundary.size(); ++k)
+        if (boundary[k] == pass) { sp.push_back(m->single_prefix[k]); sb.push_back(m->single_base[k]); }
+    m->n_interior = (int)std::count(boundary.begin(), boundary.end(), (uint8_t)0);
+    m->single_prefix.swap(sp); m->single_base.swap(sb);
+  }
   m->tile_gbase.resize(m->tile_prefix.size());
   for (size_t k = 0; k < m->tile_prefix.size(); ++k) m->tile_gbase[k] = tile_base_global(m, m->tile_prefix[k]);
   return SD_OK;
@@ -511,6 +541,7 @@ int sd_upload_model(sd_model *m, std::string &err) {
     if ((rc = up(m, m->pack_len, &d.pack_len, err))) return rc;
     d.n_groups = (int)m->group_P0.size();
     d.n_singles = (int)m->single_prefix.size();
+    d.n_interior = m->n_interior; d.tile_off = 0;
     m->single_rec.resize(m->single_prefix.size());
     for (size_t k = 0; k < m->single_prefix.size(); ++k) {
       const uint32_t P = m->single_prefix[k];

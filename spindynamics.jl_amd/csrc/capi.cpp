@@ -226,6 +226,7 @@ int sd_model_shard_info(const sd_model *m, sd_shard_info *out) {
   out->n_recv_slabs = (int64_t)m->recv_slabs.size(); out->n_send_slabs = (int64_t)m->send_slabs.size();
   out->mode = m->shard_mode; out->n_send = m->n_send; out->n_local_tiles = (int64_t)m->tile_prefix.size();
   out->n_pack = (int64_t)m->pack_len.size();
+  out->n_interior_tiles = m->n_interior;
   return SD_OK;
 }
 
@@ -283,11 +284,12 @@ int sd_apply_dev(sd_ctx *ctx, const sd_model *m, int dtype, void *out, const voi
 
 int sd_apply_sharded_dev(sd_ctx *ctx, const sd_model *m, int dtype, void *out, const void *psi, const void *halo,
                          int64_t n_local, int epilogue, double a, double b, double c_re, double c_im,
-                         const void *phi_prev, void *psi_t) {
+                         const void *phi_prev, void *psi_t, int part) {
   int rc = check_apply_args(ctx, m, dtype, out, psi, n_local);
   if (rc) return rc;
   if (n_local != m->n_local) return sd_set_err(ctx, SD_EDIM, "vector length does not match the local basis dimension");
-  if (m->n_halo > 0 && !halo) return sd_set_err(ctx, SD_EARG, "this shard needs a halo buffer");
+  if (part < 0 || part > 2) return sd_set_err(ctx, SD_EARG, "part must be 0 (all), 1 (interior) or 2 (boundary)");
+  if (m->n_halo > 0 && !halo && part != 1) return sd_set_err(ctx, SD_EARG, "this shard needs a halo buffer");
   sd_epi_args ea; ea.a = a; ea.b = b; ea.c_re = c_re; ea.c_im = c_im; ea.prev = phi_prev; ea.accv = psi_t; ea.halo = halo;
   int epi;
   switch (epilogue) {
@@ -298,7 +300,7 @@ int sd_apply_sharded_dev(sd_ctx *ctx, const sd_model *m, int dtype, void *out, c
       epi = SD_EPI_CHEB; break;
     default: return sd_set_err(ctx, SD_EARG, "unknown epilogue");
   }
-  return sd_launch_apply(ctx, m, dtype, out, psi, epi, ea);
+  return sd_launch_apply(ctx, m, dtype, out, psi, epi, ea, part);
 }
 
 int sd_apply_rescaled_dev(sd_ctx *ctx, const sd_model *m, int dtype, void *out, const void *psi, int64_t n, double a,

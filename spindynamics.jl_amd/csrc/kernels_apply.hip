@@ -62,7 +62,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_apply_tiled(sd_dev_model dm, doubl
   const V *__restrict__ halo = reinterpret_cast<const V *>(ea.halo);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int tix = blockIdx.x;
+  const int tix = blockIdx.x + dm.tile_off;
   const sd_tile_rec rec = dm.single_rec[tix];       // one 32-byte scalar load: no dependent table look-ups at start-up
   const uint32_t P = rec.prefix;
   const int64_t base = rec.base;
@@ -516,14 +516,18 @@ int launch_tiled(sd_ctx *ctx, const sd_dev_model &dm, int nt, size_t shmem, doub
 }  // namespace
 
 int sd_launch_apply(sd_ctx *ctx, const sd_model *m, int dtype, void *out, const void *psi, int epi,
-                    const sd_epi_args &ea) {
+                    const sd_epi_args &ea, int part) {
   if (!m->dev_ready) return sd_set_err(ctx, SD_EARG, "model has no device tables (created without a context)");
   if (dtype != SD_F64 && dtype != SD_C128) return sd_set_err(ctx, SD_EARG, "dtype must be SD_F64 or SD_C128");
   const bool sums = (epi == SD_EPI_DOT || epi == SD_EPI_KPM || epi == SD_EPI_RESCALE_DOT);
-  const sd_dev_model &dm = m->dm;
+  sd_dev_model dm = m->dm;
   if (dm.n_local == 0) return SD_OK;
   if (m->p >= 0) {
-    const int nt = dm.n_singles, ng = dm.n_groups;
+    // part 0: every tile; 1: interior tiles only (no halo read); 2: boundary tiles only
+    int nt = dm.n_singles;
+    const int ng = part == 0 ? dm.n_groups : 0;
+    if (part == 1) nt = dm.n_interior;
+    else if (part == 2) { dm.tile_off = dm.n_interior; nt = dm.n_singles - dm.n_interior; }
     if (sums) { int rc = sd_ensure_partials(ctx, 2 * (size_t)(nt + ng)); if (rc) return rc; }
     const int max_len = m->max_tile_len;
     const size_t esz = dtype == SD_C128 ? 16 : 8;

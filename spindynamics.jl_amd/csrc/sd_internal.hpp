@@ -87,6 +87,8 @@ struct sd_dev_model {
   const uint16_t *suf_rank;      // 2^LS entries: rank of sigma inside its sector
   // grouped path: 8 tiles related by three disjoint flippable top bonds share one workgroup / one LDS image
   int n_groups, n_singles;
+  int n_interior;                // sharded plans: the first n_interior single tiles read no halo (their partners are all owned)
+  int tile_off;                  // first tile of this launch (lets the interior / boundary parts run as separate launches)
   const uint32_t *single_prefix; // tiles not in any group (all tiles when grouping is off), processed by k_apply_tiled
   const int64_t *single_base;
   const sd_tile_rec *single_rec;
@@ -119,6 +121,7 @@ struct sd_model {
   std::vector<int32_t> pack_len;
   std::vector<uint32_t> group_P0, group_gens;  // grouped tiles (unsharded NN-chain plans only)
   std::vector<uint32_t> single_prefix;
+  int n_interior = 0;
   int group_ngen = 0;          // generator bonds per group (2 or 3)
   std::vector<int64_t> single_base;
   std::vector<sd_tile_rec> single_rec;
@@ -160,7 +163,7 @@ struct sd_epi_args {
 // Launches the apply with the chosen epilogue.  When the epilogue produces
 // partial sums, the reduced values land in ctx->d_scalars[0..1] (device).
 int sd_launch_apply(sd_ctx *ctx, const sd_model *m, int dtype, void *out, const void *psi, int epi,
-                    const sd_epi_args &ea);
+                    const sd_epi_args &ea, int part = 0);
 int sd_launch_observable(sd_ctx *ctx, const sd_model *m, int dtype, const void *psi, int mode, double *out_host);
 int sd_launch_pack(sd_ctx *ctx, const sd_model *m, int dtype, const void *psi, void *sendbuf);
 int sd_launch_fill_randn_local(sd_ctx *ctx, const sd_model *m, int dtype, void *x, uint64_t seed);

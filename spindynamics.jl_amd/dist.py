@@ -27,6 +27,8 @@ class ShardedOperator:
         self.mode = "class" if int(info.mode) == 1 else "range"
         self.n_send = int(info.n_send)
         self._send = {}
+        self.overlap = True               # run interior tiles while the halo exchange is in flight
+        self.n_interior_tiles = int(info.n_interior_tiles)
         self.n_local, self.n_halo = int(info.n_local), int(info.n_halo)
         self.row_lo, self.row_hi = int(info.row_lo), int(info.row_hi)
         self.recv_slabs, self.send_slabs = model.shard_slabs()
@@ -71,14 +73,14 @@ class ShardedOperator:
     def halo_bytes(self, itemsize=16):
         return self.n_halo * itemsize
 
-    def exchange(self, psi, group=None):
-        """Fill the halo buffer from the owning ranks' copies of psi (collective over all ranks)."""
+    def exchange_start(self, psi, group=None):
+        """Post the halo exchange for psi (pack + grouped isend/irecv) and return the pending requests."""
         halo = self.halo(psi)
         if self._exchange_fn is not None:
             self._exchange_fn(self, psi, halo)
-            return halo
+            return halo, []
         if self.world == 1:
-            return halo
+            return halo, []
         import torch
         import torch.distributed as dist
         out = self.pack(psi) if self.mode == "class" else psi     # what the send slabs index
@@ -90,12 +92,16 @@ class ShardedOperator:
             ops.append(dist.P2POp(dist.irecv, dst[off - nl:off - nl + cnt], peer, group))
         for (peer, off, cnt, _g) in self.send_slabs:
             ops.append(dist.P2POp(dist.isend, src[off:off + cnt], peer, group))
-        if ops:
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
+        return halo, (dist.batch_isend_irecv(ops) if ops else [])
+
+    def exchange(self, psi, group=None):
+        """Fill the halo buffer from the owning ranks' copies of psi (collective over all ranks)."""
+        halo, reqs = self.exchange_start(psi, group)
+        for req in reqs:
+            req.wait()
         return halo
 
-    def _launch(self, out, psi, halo, epilogue, a=1.0, b=0.0, c=0j, prev=None, acc=None):
+    def _launch(self, out, psi, halo, epilogue, a=1.0, b=0.0, c=0j, prev=None, acc=None, part=0):
         import torch
         if self.n_local == 0:          # a rank may own no tile when there are fewer tiles than ranks
             return out
@@ -107,20 +113,34 @@ class ShardedOperator:
                                          halo.data_ptr() if self.n_halo else None, self.n_local, epilogue,
                                          float(a), float(b), c.real, c.imag,
                                          prev.data_ptr() if prev is not None else None,
-                                         acc.data_ptr() if acc is not None else None), m.ctx.h)
+                                         acc.data_ptr() if acc is not None else None, part), m.ctx.h)
         return out
 
+    def _apply(self, out, psi, group, epilogue, exchange=True, **kw):
+        """Exchange overlapped with compute: the interior tiles (all partners owned) run while the halo is in flight,
+        the boundary tiles after it has landed."""
+        if not exchange:
+            return self._launch(out, psi, self.halo(psi), epilogue, **kw)
+        halo, reqs = self.exchange_start(psi, group)
+        if not reqs or not self.overlap:
+            for req in reqs:
+                req.wait()
+            return self._launch(out, psi, halo, epilogue, **kw)
+        self._launch(out, psi, halo, epilogue, part=1, **kw)
+        for req in reqs:
+            req.wait()                 # the compute stream now waits for the received halo
+        return self._launch(out, psi, halo, epilogue, part=2, **kw)
+
     def apply(self, out, psi, group=None, exchange=True):
-        """out = (H psi)[row_lo:row_hi]; the halo is refreshed first (pass exchange=False to reuse it)."""
-        halo = self.exchange(psi, group) if exchange else self.halo(psi)
-        return self._launch(out, psi, halo, 0)
+        """out = H psi on the owned rows; the halo is refreshed first (pass exchange=False to reuse it)."""
+        return self._apply(out, psi, group, 0, exchange)
 
     def apply_rescaled(self, out, psi, a, b, group=None):
-        return self._launch(out, psi, self.exchange(psi, group), 1, a, b)
+        return self._apply(out, psi, group, 1, a=a, b=b)
 
     def cheb_step(self, phi_next, phi_curr, phi_prev, psi_t, a, b, c, group=None):
         """One fused Chebyshev term (src/TimeEvolution/Chebyshev.jl:110-121) on this shard."""
-        return self._launch(phi_next, phi_curr, self.exchange(phi_curr, group), 2, a, b, c, phi_prev, psi_t)
+        return self._apply(phi_next, phi_curr, group, 2, a=a, b=b, c=c, prev=phi_prev, acc=psi_t)
 
     def chebyshev_time_evolve(self, psi0, dt, cheb_n=100, Ebounds=(-1.0, 1.0), group=None):
         """chebyshev_time_evolve (src/TimeEvolution/Chebyshev.jl:61-124) on a sharded ComplexF64 state (psi0 = this

@@ -38,10 +38,17 @@ def test_virtual_shards_bit_identical(pkg, L, nup, P, ls, mode, monkeypatch):
                 assert cnt == cnt2
                 hq[ro - ops[q].n_local:ro - ops[q].n_local + cnt] = outs[r][so:so + cnt]
     got = np.empty_like(psi)
+    n_int = 0
     for r in range(P):
-        out = torch.empty_like(bufs[r])
-        ops[r].apply(out, bufs[r], exchange=False)
+        out = torch.full_like(bufs[r], float("nan"))
+        if r % 2 == 0:
+            ops[r].apply(out, bufs[r], exchange=False)
+        else:   # the overlapped form: interior tiles (no halo read) and boundary tiles as separate launches
+            ops[r]._launch(out, bufs[r], ops[r].halo(bufs[r]), 0, part=1)
+            ops[r]._launch(out, bufs[r], ops[r].halo(bufs[r]), 0, part=2)
+        n_int += ops[r].n_interior_tiles
         got[ops[r].model.local_rows()] = out.cpu().numpy()
+    assert n_int > 0 or L <= 14          # (two-tile plans have no interior tile)
     assert np.array_equal(got, want)
     assert sum(o.n_local for o in ops) == full.N
 
