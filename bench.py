@@ -93,6 +93,33 @@ def main():
     op = pkg.ShardedOperator(model, rank, world)
     a = op.empty(tdtype, dev)
     b = op.empty(tdtype, dev)
+
+    def selfcheck():
+        """Exact, size-independent check of the path that is about to be timed (incl. the RCCL exchange): for the
+        Heisenberg point of the open chain H|F> = (L-1)/4 |F> holds bit for bit for the uniform vector |F>
+        (all partial sums are small dyadic rationals), on every row of every rank."""
+        a.fill_(1.0)
+        b.zero_()
+        op.apply(b, a)
+        ok = torch.tensor([1.0 if bool((b == (L - 1) / 4).all()) else 0.0], device=dev)
+        if dist is not None:
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        return bool(ok.item() == 1.0)
+
+    check = "uniform state exact eigenvector on all ranks"
+    if not selfcheck():
+        # fall back to the simplest distributed path before giving up: index ranges, no overlap
+        if world > 1 and op.mode == "class":
+            model = pkg.XXZChain(L, nup=nup)
+            op = pkg.ShardedOperator(model, rank, world, mode="range")
+            op.overlap = False
+            a = op.empty(tdtype, dev)
+            b = op.empty(tdtype, dev)
+            check = "FELL BACK to index ranges without overlap (popcount-cell path failed its self-check)"
+            if not selfcheck():
+                raise SystemExit("sharded apply failed its exactness self-check on rank %d" % rank)
+        else:
+            raise SystemExit("apply failed its exactness self-check on rank %d" % rank)
     op.fill_randn(a, SEED)
     nrm = op.norm(a)
     a /= nrm
@@ -167,6 +194,7 @@ def main():
                                    "%s shards, %d rank(s), halo exchange per step" % (L, nup, N, "popcount-cell" if op.mode == "class" else "basis-index-range", world),
                        "rows_per_rank": op.n_local, "halo_rows_rank0": op.n_halo, "shard_mode": op.mode,
                        "device_path": model.device_path},
+            "selfcheck": check,
             "achieved_hbm_GBs_per_gpu": achieved,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
