@@ -237,6 +237,12 @@ typedef struct sd_slab {
 /* Re-plans the model as shard `rank` of `nranks` (nranks == 1 restores the
  * unsharded plan).  Must be called before any apply on that model. */
 int sd_model_set_shard(sd_model *m, int rank, int nranks);
+/* One KPM moment step on a shard (src/KPM_Sqw.jl:106-117), ComplexF64 device vectors of n_local elements:
+ * first != 0: v_next = (H v_curr - b v_curr)/a; else v_next = 2 (H v_curr - b v_curr)/a - v_prev.
+ * sums_out[0..1] = this rank's { Re<phi|v_next>, |v_next|^2 }: all-reduce over the ranks for mu_n and the norm. */
+int sd_kpm_step_sharded_dev(sd_ctx *ctx, const sd_model *m, void *v_next_dev, const void *v_curr_dev, const void *halo_dev,
+                            const void *v_prev_dev, const void *phi_dev, int64_t n_local, double a, double b, int first,
+                            double *sums_out);
 /* mode: -1 auto (env SD_SHARD_MODE=range|class, default class when the model allows it), 0 index ranges, 1 popcount cells */
 int sd_model_set_shard_mode(sd_model *m, int rank, int nranks, int mode);
 /* local tiles in natural order: offset in the local vector, GLOBAL basis index of the first row, rows (arrays of

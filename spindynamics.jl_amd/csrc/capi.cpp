@@ -282,6 +282,22 @@ int sd_apply_dev(sd_ctx *ctx, const sd_model *m, int dtype, void *out, const voi
   return sd_launch_apply(ctx, m, dtype, out, psi, SD_EPI_PLAIN, ea);
 }
 
+int sd_kpm_step_sharded_dev(sd_ctx *ctx, const sd_model *m, void *v_next, const void *v_curr, const void *halo,
+                            const void *v_prev, const void *phi, int64_t n_local, double a, double b, int first,
+                            double *sums_out) {
+  // one KPM recursion step on this shard (src/KPM_Sqw.jl:106-117): first != 0: v_next = H~ v_curr; else
+  // v_next = 2 H~ v_curr - v_prev.  sums_out = local { Re<phi|v_next>, |v_next|^2 } (all-reduce them over the ranks).
+  int rc = check_apply_args(ctx, m, SD_C128, v_next, v_curr, n_local);
+  if (rc) return rc;
+  if (n_local != m->n_local) return sd_set_err(ctx, SD_EDIM, "vector length does not match the local basis dimension");
+  if (!phi || !sums_out || (!first && !v_prev)) return sd_set_err(ctx, SD_EARG, "null argument");
+  if (m->n_halo > 0 && !halo) return sd_set_err(ctx, SD_EARG, "this shard needs a halo buffer");
+  sd_epi_args ea; ea.a = a; ea.b = b; ea.prev = v_prev; ea.phi = phi; ea.halo = halo;
+  rc = sd_launch_apply(ctx, m, SD_C128, v_next, v_curr, first ? SD_EPI_RESCALE_DOT : SD_EPI_KPM, ea, 0);
+  if (rc) return rc;
+  return sd_read_scalars(ctx, 0, 2, sums_out);
+}
+
 int sd_apply_sharded_dev(sd_ctx *ctx, const sd_model *m, int dtype, void *out, const void *psi, const void *halo,
                          int64_t n_local, int epilogue, double a, double b, double c_re, double c_im,
                          const void *phi_prev, void *psi_t, int part) {

@@ -164,6 +164,88 @@ class ShardedOperator:
             prev, cur, nxt = cur, nxt, prev
         return acc
 
+    # ---- KPM on a sharded state (BASELINE config 5: L=36 over 8 GPUs) ----
+    def _allreduce(self, vals, device, group=None):
+        import torch
+        import torch.distributed as dist
+        if self.world == 1 or self._exchange_fn is not None:
+            return [float(v) for v in vals]
+        t = torch.tensor(list(vals), dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        return [float(v) for v in t.tolist()]
+
+    def dot(self, x, y, group=None):
+        """<x|y> over all ranks (conjugate-linear in x)."""
+        import torch
+        v = torch.vdot(x, y) if self.n_local else torch.zeros((), dtype=x.dtype, device=x.device)
+        re, im = self._allreduce([v.real.item(), v.imag.item() if v.is_complex() else 0.0], x.device, group)
+        return complex(re, im)
+
+    def Sz_q_vector(self, psi0, q):
+        """Sz_q_vector on the owned rows (purely local: a diagonal operator)."""
+        import torch
+        phi = torch.empty(self.n_local, dtype=torch.complex128, device=psi0.device)
+        if self.n_local:
+            m = self.model
+            m.ctx.set_stream(torch.cuda.current_stream(psi0.device).cuda_stream)
+            code = _lib.SD_C128 if psi0.is_complex() else _lib.SD_F64
+            check(lib().sd_szq_dev(m.ctx.h, m.h, code, psi0.data_ptr(), self.n_local, float(q), phi.data_ptr()), m.ctx.h)
+        return phi
+
+    def kpm_moments(self, phi, M, a, b, group=None):
+        """compute_chebyshev_moments (src/KPM_Sqw.jl:95-128) for a normalised sharded phi; returns mu[0..M)."""
+        import ctypes as C
+        import numpy as np
+        import torch
+        if M < 2:
+            raise _lib.ArgumentError("kpm_m must be >= 2")
+        m = self.model
+        mu = np.zeros(M)
+        v_prev, v_curr, v_next = phi.clone(), torch.empty_like(phi), torch.empty_like(phi)
+        mu[0] = self.dot(phi, v_prev, group).real
+        sums = (C.c_double * 2)()
+        for k in range(1, M):
+            src = v_prev if k == 1 else v_curr
+            dst = v_curr if k == 1 else v_next
+            halo = self.exchange(src, group)
+            loc = [0.0, 0.0]
+            if self.n_local:
+                m.ctx.set_stream(torch.cuda.current_stream(phi.device).cuda_stream)
+                check(lib().sd_kpm_step_sharded_dev(m.ctx.h, m.h, dst.data_ptr(), src.data_ptr(),
+                                                    halo.data_ptr() if self.n_halo else None,
+                                                    v_prev.data_ptr(), phi.data_ptr(), self.n_local, float(a), float(b),
+                                                    1 if k == 1 else 0, sums), m.ctx.h)
+                loc = [sums[0], sums[1]]
+            tot = self._allreduce(loc, phi.device, group)
+            mu[k] = tot[0]
+            if k >= 2:
+                nv = float(np.sqrt(tot[1]))
+                if nv > 1e3:                       # src/KPM_Sqw.jl:117-121
+                    v_next /= nv
+                v_prev, v_curr, v_next = v_curr, v_next, v_prev
+        return mu
+
+    def kpm_sqw(self, psi0, q_list, omega, a, b, kpm_m=200, kernel="jackson", group=None):
+        """kpm_sqw (src/KPM_Sqw.jl:191-256) with explicit (a, b) on a sharded ComplexF64/Float64 psi0."""
+        import numpy as np
+        import torch
+        from .solvers import get_kernel, kpm_reconstruct
+        psic = psi0.to(torch.complex128)
+        tmp = torch.empty_like(psic)
+        self.apply(tmp, psic, group)
+        E0 = self.dot(psic, tmp, group).real
+        S = np.zeros((len(q_list), len(omega)))
+        g = get_kernel(kpm_m, kernel)
+        for iq, q in enumerate(q_list):
+            phi = self.Sz_q_vector(psic, float(q))
+            n2 = self.dot(phi, phi, group).real
+            if n2 == 0:
+                continue
+            phi /= np.sqrt(n2)
+            mu = self.kpm_moments(phi, kpm_m, a, b, group) * g
+            S[iq] = n2 * kpm_reconstruct(mu, omega, a, b, E0)
+        return S
+
     def fill_randn(self, x, seed):
         """Counter-based N(0,1) keyed by the GLOBAL element index: identical for every sharding."""
         import torch

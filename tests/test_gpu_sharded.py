@@ -93,3 +93,23 @@ def test_sharded_fill_randn_is_sharding_independent(pkg, mode, monkeypatch):
         op.fill_randn(x, 1234)
         got[m.local_rows()] = x.cpu().numpy()
     assert np.array_equal(got, ref)
+
+
+def test_sharded_kpm_driver_matches_oracle(pkg, O, monkeypatch):
+    """config 5 in miniature (driver logic with one rank; the multi-rank exchange is covered above): S(q,w) via the
+    sharded KPM driver == the oracle within BASELINE's 1e-8."""
+    import torch
+    monkeypatch.setenv("SD_SUFFIX_BITS", "8")
+    L, nup = 14, 7
+    m = pkg.XXZChain(L, nup=nup)
+    r = O.XXZChain(L, nup=nup)
+    rng = np.random.default_rng(8)
+    psi0 = rng.standard_normal(m.N)
+    psi0 /= np.linalg.norm(psi0)
+    a, b = O.rescaling_from_bounds(-L / 2, L / 2)
+    q = pkg.momenta(m)[:4]
+    omega = np.arange(-3.0, 5.0, 0.1)
+    op = pkg.ShardedOperator(m, 0, 1)
+    S = op.kpm_sqw(torch.from_numpy(psi0).cuda(), q, omega, a, b, kpm_m=96)
+    S2 = O.kpm_sqw(r, psi0, q, omega, a, b, kpm_m=96)
+    assert np.abs(S - S2).max() <= 1e-8 * max(1.0, np.abs(S2).max())
