@@ -16,7 +16,9 @@
 module SpinDynamicsMI
 
 export Model, build_model, XXZChain, momenta, apply_H!, apply_rescaled_H!, Sz_q_vector,
-       groundstate, time_evolve, dynamical_structure_factor
+       groundstate, time_evolve, structure_factor, dynamical_structure_factor,
+       magnetization_per_site, connected_correlations, structure_factor_Sq,
+       domain_wall_state, neel_state, polarized_state, polarized_state_with_flips
 
 const libspindyn = get(ENV, "SPINDYN_LIB", joinpath(@__DIR__, "..", "spindynamics.jl_amd", "libspindyn.so"))
 
@@ -124,6 +126,41 @@ function Sz_q_vector(model::Model, psi0::AbstractVector{T}, q::Float64) where {T
                 model.ctx.h, model.h, dtype_code(eltype(x)), x, length(x), q, phi), model.ctx.h)
     return phi
 end
+
+# ---- Observables (src/Observables.jl) and InitialStates (src/InitialStates.jl) ------
+function _obs(fname::Symbol, ψ::AbstractVector, model::Model, nout::Int)
+    x = eltype(ψ) <: Complex ? Vector{ComplexF64}(ψ) : Vector{Float64}(ψ)
+    outs = [Vector{Float64}(undef, model.L) for _ in 1:nout]
+    if nout == 1
+        check(ccall((fname, libspindyn), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Int64, Ptr{Float64}),
+                    model.ctx.h, model.h, dtype_code(eltype(x)), x, length(x), outs[1]), model.ctx.h)
+    else
+        check(ccall((fname, libspindyn), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{Float64}),
+                    model.ctx.h, model.h, dtype_code(eltype(x)), x, length(x), outs[1], outs[2]), model.ctx.h)
+    end
+    return outs
+end
+magnetization_per_site(ψ::AbstractVector, model::Model) = _obs(:sd_magnetization, ψ, model, 1)[1]
+connected_correlations(ψ::AbstractVector, model::Model) = _obs(:sd_connected_correlations, ψ, model, 1)[1]
+function structure_factor_Sq(ψ::AbstractVector, model::Model)
+    q, S = _obs(:sd_structure_factor, ψ, model, 2)
+    return Dict{Float64,Float64}(q[n] => S[n] for n in 1:model.L)       # src/Observables.jl:103-108
+end
+structure_factor(model::Model, ψ::AbstractVector) = structure_factor_Sq(ψ, model)   # src/PublicAPI.jl:101-106
+
+function _one_hot(model::Model, kind::Integer, flips::Vector{Int}=Int[])
+    idx = Ref{Int64}(0)
+    f = Cint.(flips)
+    check(ccall((:sd_initial_state_index, libspindyn), Cint, (Ptr{Cvoid}, Cint, Ptr{Cint}, Cint, Ref{Int64}),
+                model.h, kind, f, length(f), idx), model.ctx.h)      # SD_EARG -> ArgumentError, as the reference throws
+    ψ0 = zeros(Float64, length(model))
+    ψ0[idx[] + 1] = 1.0
+    return ψ0
+end
+domain_wall_state(model::Model) = _one_hot(model, 0)
+neel_state(model::Model) = _one_hot(model, 1)
+polarized_state(model::Model; up::Bool=true) = _one_hot(model, up ? 2 : 3)
+polarized_state_with_flips(model::Model, flips::Vector{Int}) = _one_hot(model, 4, flips)
 
 # ---- PublicAPI (src/PublicAPI.jl) ---------------------------------------------------
 function groundstate(model::Model; method::Symbol=:lanczos, lanc_m::Int=100, tol::Float64=1e-12,
