@@ -79,12 +79,18 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    backend = os.environ.get("SD_BENCH_BACKEND", "nccl")   # "gloo": rehearsal of the N>1 control flow on a 1-GPU box
+    if backend != "nccl":
+        local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     L, nup = args.L, args.L // 2
     tdtype = torch.complex128 if args.dtype == "c128" else torch.float64
@@ -101,7 +107,7 @@ def main():
         a.fill_(1.0)
         b.zero_()
         op.apply(b, a)
-        ok = torch.tensor([1.0 if bool((b == (L - 1) / 4).all()) else 0.0], device=dev)
+        ok = torch.tensor([1.0 if bool((b == (L - 1) / 4).all()) else 0.0], device=dev if backend == "nccl" else "cpu")
         if dist is not None:
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         return bool(ok.item() == 1.0)
@@ -146,7 +152,7 @@ def main():
     t1 = time.perf_counter()
     elapsed = t1 - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ev_ms = ev0.elapsed_time(ev1) / args.steps  # per step, device time on the launch stream

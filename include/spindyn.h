@@ -191,6 +191,17 @@ int sd_connected_correlations_dev(sd_ctx *ctx, const sd_model *m, int dtype, con
 /* structure_factor_Sq   src/Observables.jl:100-109 : q_out[k] = 2 pi k / L, S_out[k] = real(fft(C_r))[k] */
 int sd_structure_factor(sd_ctx *ctx, const sd_model *m, int dtype, const void *psi_host, int64_t n, double *q_out, double *S_out);
 int sd_structure_factor_dev(sd_ctx *ctx, const sd_model *m, int dtype, const void *psi_dev, int64_t n, double *q_out, double *S_out);
+/* create_spin_operator(site, op)(psi, model)   src/Hamiltonian.jl:49-136.  site is 1-based.  S^z is diagonal and works
+ * in any basis; S^+, S^-, S^x, S^y change the magnetisation and are rejected in a fixed-nup sector (SD_EARG), as the
+ * reference does.  out has psi's element type; S^y needs a ComplexF64 psi (SD_EARG otherwise: the reference's
+ * accumulation of +-0.5im*psi into a Float64 result raises InexactError). */
+#define SD_SPIN_Z 0
+#define SD_SPIN_PLUS 1
+#define SD_SPIN_MINUS 2
+#define SD_SPIN_X 3
+#define SD_SPIN_Y 4
+int sd_spin_operator(sd_ctx *ctx, const sd_model *m, int dtype, int site, int op, const void *psi_host, int64_t n,
+                     void *out_host);
 /* InitialStates (src/InitialStates.jl:9-130): 0-based basis index of the one-hot state; SD_EARG when the
  * configuration is not in the basis.  flips: 1-based sites for SD_STATE_POLARIZED_FLIPS. */
 #define SD_STATE_DOMAIN_WALL 0

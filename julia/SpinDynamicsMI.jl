@@ -15,7 +15,7 @@
 #   groundstate, time_evolve, dynamical_structure_factor   src/PublicAPI.jl:25-155
 module SpinDynamicsMI
 
-export Model, build_model, XXZChain, momenta, apply_H!, apply_rescaled_H!, Sz_q_vector,
+export Model, build_model, XXZChain, momenta, apply_H!, apply_rescaled_H!, Sz_q_vector, create_spin_operator,
        groundstate, time_evolve, structure_factor, dynamical_structure_factor,
        magnetization_per_site, connected_correlations, structure_factor_Sq,
        domain_wall_state, neel_state, polarized_state, polarized_state_with_flips
@@ -125,6 +125,23 @@ function Sz_q_vector(model::Model, psi0::AbstractVector{T}, q::Float64) where {T
     check(ccall((:sd_szq, libspindyn), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Int64, Float64, Ptr{Cvoid}),
                 model.ctx.h, model.h, dtype_code(eltype(x)), x, length(x), q, phi), model.ctx.h)
     return phi
+end
+
+# create_spin_operator(site, op_type)  -- src/Hamiltonian.jl:49-136
+const _SPIN_OPS = Dict(:z => 0, :plus => 1, :minus => 2, :x => 3, :y => 4)
+function create_spin_operator(site::Int, op_type::Symbol)
+    site >= 1 || throw(ArgumentError("site must be at least 1"))
+    haskey(_SPIN_OPS, op_type) ||
+        throw(ArgumentError("unsupported spin operator: \$op_type; expected :z, :plus, :minus, :x, or :y"))
+    function operator(ψ::AbstractVector{T}, model::Model) where {T}
+        x = T <: Complex ? Vector{ComplexF64}(ψ) : Vector{Float64}(ψ)
+        out = similar(x)
+        check(ccall((:sd_spin_operator, libspindyn), Cint,
+                    (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Cint, Cint, Ptr{Cvoid}, Int64, Ptr{Cvoid}),
+                    model.ctx.h, model.h, dtype_code(eltype(x)), site, _SPIN_OPS[op_type], x, length(x), out), model.ctx.h)
+        return out
+    end
+    return operator
 end
 
 # ---- Observables (src/Observables.jl) and InitialStates (src/InitialStates.jl) ------

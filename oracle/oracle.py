@@ -166,6 +166,45 @@ def Sz_q_vector(model, psi0, q):
     return phi
 
 
+def spin_operator(model, site, op_type, psi):
+    """create_spin_operator(site, op_type)(psi, model) -- src/Hamiltonian.jl:49-136, in the reference's scatter form
+    (numpy loops; small models only).  op_type in {"z","plus","minus","x","y"}."""
+    if site < 1 or op_type not in ("z", "plus", "minus", "x", "y"):
+        raise OracleError(1)
+    if site > model.L:
+        raise OracleError(1)
+    psi = np.asarray(psi)
+    states = model.states
+    if len(psi) != len(states):
+        raise OracleError(2)
+    if model.nup is not None and op_type != "z":
+        raise OracleError(1)
+    bit = site - 1
+    res = np.zeros(len(psi), dtype=psi.dtype)   # zeros(T, length(psi)): a complex update of a real result is an error upstream
+    for idx, st in enumerate(states):
+        st = int(st)
+        cur = (st >> bit) & 1
+        if op_type == "z":
+            res[idx] = (0.5 if cur else -0.5) * psi[idx]
+            continue
+        if op_type == "plus" and cur != 0:
+            continue
+        if op_type == "minus" and cur != 1:
+            continue
+        j = model.lookup(st ^ (1 << bit))
+        if j == 0:
+            continue
+        if op_type in ("plus", "minus"):
+            res[j - 1] += psi[idx]
+        elif op_type == "x":
+            res[j - 1] += 0.5 * psi[idx]
+        else:
+            if not np.iscomplexobj(res):
+                raise TypeError("InexactError: S^y of a Float64 vector")
+            res[j - 1] += (-0.5j if cur == 0 else 0.5j) * psi[idx]
+    return res
+
+
 def symtridiag_eig(d, e, vectors=True):
     d = _as_f64(d)
     e = _as_f64(e)

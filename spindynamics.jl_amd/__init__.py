@@ -9,7 +9,8 @@ the library or a device is missing -- there is no CPU fallback.
 from ._lib import (ArgumentError, Context, DimensionMismatch, SpinDynError, ZeroNormError, default_context, lib,
                    LIB_PATH, PROTOTYPES)
 from .model import Model, XXZChain, build_model, long_range_hopping, momenta, nn_hopping
-from .hamiltonian import Sz_q_vector, apply_H, apply_rescaled_H, bit_at, cheb_step, flip_bits, sz_value
+from .hamiltonian import (Sz_q_vector, apply_H, apply_rescaled_H, bit_at, cheb_step, create_spin_operator, flip_bits,
+                          sz_value)
 from .solvers import (chebyshev_coeffs, chebyshev_time_evolve, compute_chebyshev_moments, estimate_energy_bounds,
                       get_kernel, get_rescaling_params, kpm_reconstruct, kpm_sqw, kpm_sw, krylov_time_evolve,
                       lanczos_extremal, lanczos_groundstate, lanczos_sqw, lanczos_tridiag, rescaling_from_bounds,

@@ -504,6 +504,33 @@ int sd_structure_factor_dev(sd_ctx *ctx, const sd_model *m, int dtype, const voi
   return obs_dev(ctx, m, dtype, psi_dev, n, 2, S_out, q_out);
 }
 
+int sd_spin_operator(sd_ctx *ctx, const sd_model *m, int dtype, int site, int op, const void *psi_host, int64_t n,
+                     void *out_host) {
+  // create_spin_operator(site, op)(psi, model)  -- src/Hamiltonian.jl:49-136
+  if (!ctx) return SD_EARG;
+  if (!m || !psi_host || !out_host) return sd_set_err(ctx, SD_EARG, "null argument");
+  if (site < 1) return sd_set_err(ctx, SD_EARG, "site must be at least 1");                                    // :50
+  if (op < SD_SPIN_Z || op > SD_SPIN_Y) return sd_set_err(ctx, SD_EARG, "unsupported spin operator");        // :52-55
+  if (site > m->L) return sd_set_err(ctx, SD_EARG, "site is outside the model");                             // :60-61
+  if (dtype != SD_F64 && dtype != SD_C128) return sd_set_err(ctx, SD_EARG, "bad dtype");
+  if (n != m->N) return sd_set_err(ctx, SD_EDIM, "state vector length does not match the basis");             // :63-66
+  if (m->nup >= 0 && op != SD_SPIN_Z)                                                                          // :68-73
+    return sd_set_err(ctx, SD_EARG, "operator changes total magnetization and cannot be applied within a fixed-nup sector");
+  if (op == SD_SPIN_Y && dtype != SD_C128)   // result[...] += ±0.5im*psi into zeros(Float64) is an InexactError upstream (:118-127)
+    return sd_set_err(ctx, SD_EARG, "S^y of a Float64 vector is complex: pass ComplexF64");
+  if (m->nranks != 1) return sd_set_err(ctx, SD_EARG, "needs an unsharded model");
+  const size_t bin = (size_t)n * (dtype == SD_C128 ? 16 : 8), bout = bin;
+  TmpDev din(ctx), dout(ctx);
+  int rc;
+  if ((rc = din.alloc(bin)) || (rc = dout.alloc(bout))) return rc;
+  SD_HIP(ctx, hipMemcpyAsync(din.p, psi_host, bin, hipMemcpyHostToDevice, ctx->stream));
+  rc = sd_launch_spin_op(ctx, m, dtype, site, op, din.p, dout.p);
+  if (rc) return rc;
+  SD_HIP(ctx, hipMemcpyAsync(out_host, dout.p, bout, hipMemcpyDeviceToHost, ctx->stream));
+  SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SD_OK;
+}
+
 int sd_initial_state_index(const sd_model *m, int kind, const int *flips, int nflips, int64_t *idx0_out) {
   if (!m || !idx0_out || nflips < 0 || (nflips && !flips)) return SD_EARG;
   const int L = m->L;

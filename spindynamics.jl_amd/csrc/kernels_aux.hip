@@ -159,6 +159,41 @@ __global__ __launch_bounds__(256) void k_fill_randn_tiles(sd_dev_model dm, doubl
       x[lb * per + i] = sd_randn_at(seed, (uint64_t)(gb * per + i));
   }
 }
+
+// ---- create_spin_operator(site, op)  (src/Hamiltonian.jl:49-136) in gather form ----
+// op: 0 z, 1 plus, 2 minus, 3 x, 4 y.  z is diagonal; the others change the magnetisation and exist in the full basis
+// only (the reference throws in a sector, :68-73), where the flipped configuration is idx ^ (1 << (site-1)).
+// out has psi's element type; y needs ComplexF64 (the host rejects a real psi, where the reference raises InexactError).
+template <int NC>
+__global__ __launch_bounds__(256) void k_spin_op(sd_dev_model dm, int bit_pos, int op, const double *__restrict__ psi,
+                                                 double *__restrict__ out) {
+  const bool full = dm.nup < 0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < dm.N; idx += stride) {
+    uint64_t s;
+    if (full) s = (uint64_t)idx;
+    else s = unrank_g(dm, idx);
+    const bool up = (s >> bit_pos) & 1;
+    double xr, xi = 0.0;
+    if (op == 0) {
+      const double z = up ? 0.5 : -0.5;
+      xr = z * psi[idx * NC];
+      if (NC == 2) xi = z * psi[idx * NC + 1];
+    } else {
+      const int64_t j = idx ^ ((int64_t)1 << bit_pos);        // full basis only
+      const double pr = psi[j * NC], pi = NC == 2 ? psi[j * NC + 1] : 0.0;
+      if (op == 1) { xr = up ? pr : 0.0; xi = up ? pi : 0.0; }            // S+ : result[flip(s)] += psi[s] for bit(s) = 0
+      else if (op == 2) { xr = up ? 0.0 : pr; xi = up ? 0.0 : pi; }       // S-
+      else if (op == 3) { xr = 0.5 * pr; xi = 0.5 * pi; }                 // Sx
+      else {                                                              // Sy: -0.5i from a down source, +0.5i from an up source
+        const double c = up ? -0.5 : 0.5;                                 // result[j'] += c*i * psi[s], j' has the opposite bit of s
+        xr = -c * pi; xi = c * pr;
+      }
+    }
+    out[idx * NC] = xr;
+    if (NC == 2) out[idx * NC + 1] = xi;
+  }
+}
 }  // namespace
 
 // mode 0: out[L] = magnetization per site; mode 1: out[L] = lag sums R_r.  psi is a device vector.
@@ -207,6 +242,18 @@ int sd_launch_fill_randn_local(sd_ctx *ctx, const sd_model *m, int dtype, void *
   if (m->p < 0) return sd_k_fill_randn(ctx, (double *)x, dm.N * per, seed, 0);
   if (dm.n_tiles == 0) return SD_OK;
   hipLaunchKernelGGL(k_fill_randn_tiles, dim3(std::min(dm.n_tiles, 8192)), dim3(256), 0, ctx->stream, dm, (double *)x, per, seed);
+  SD_HIP(ctx, hipGetLastError());
+  return SD_OK;
+}
+
+int sd_launch_spin_op(sd_ctx *ctx, const sd_model *m, int dtype, int site, int op, const void *psi, void *out) {
+  if (!m->dev_ready) return sd_set_err(ctx, SD_EARG, "model has no device tables (created without a context)");
+  const sd_dev_model &dm = m->dm;
+  int64_t nb = (dm.N + 255) / 256;
+  if (nb > 16384) nb = 16384;
+  if (nb < 1) nb = 1;
+  if (dtype == SD_C128) hipLaunchKernelGGL(k_spin_op<2>, dim3((unsigned)nb), dim3(256), 0, ctx->stream, dm, site - 1, op, (const double *)psi, (double *)out);
+  else hipLaunchKernelGGL(k_spin_op<1>, dim3((unsigned)nb), dim3(256), 0, ctx->stream, dm, site - 1, op, (const double *)psi, (double *)out);
   SD_HIP(ctx, hipGetLastError());
   return SD_OK;
 }

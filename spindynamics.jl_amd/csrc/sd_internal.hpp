@@ -167,6 +167,7 @@ int sd_launch_apply(sd_ctx *ctx, const sd_model *m, int dtype, void *out, const 
 int sd_launch_observable(sd_ctx *ctx, const sd_model *m, int dtype, const void *psi, int mode, double *out_host);
 int sd_launch_pack(sd_ctx *ctx, const sd_model *m, int dtype, const void *psi, void *sendbuf);
 int sd_launch_fill_randn_local(sd_ctx *ctx, const sd_model *m, int dtype, void *x, uint64_t seed);
+int sd_launch_spin_op(sd_ctx *ctx, const sd_model *m, int dtype, int site, int op, const void *psi, void *out);
 int sd_launch_szq(sd_ctx *ctx, const sd_model *m, int dtype_in, const void *psi0, double q, void *phi);
 
 // BLAS-1 style kernels on device vectors of `n` doubles (n = nc * N).

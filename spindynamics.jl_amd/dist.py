@@ -16,6 +16,18 @@ from . import _lib
 from ._lib import check, lib
 
 
+class _StagedRequests:
+    """wait() for a host-staged exchange: complete the gloo requests, then copy the received halo to the device."""
+
+    def __init__(self, reqs, dst_dev, dst_host):
+        self.reqs, self.dst_dev, self.dst_host = reqs, dst_dev, dst_host
+
+    def wait(self):
+        for r in self.reqs:
+            r.wait()
+        self.dst_dev.copy_(self.dst_host)
+
+
 class ShardedOperator:
     def __init__(self, model, rank, world, exchange_fn=None, mode=None, pack_fn=None):
         self.model = model
@@ -87,12 +99,21 @@ class ShardedOperator:
         src = torch.view_as_real(out) if out.is_complex() else out
         dst = torch.view_as_real(halo) if halo.is_complex() else halo
         nl = self.n_local
+        staged = src.is_cuda and dist.get_backend(group) == "gloo"
+        if staged:
+            # rehearsal only (several ranks sharing one GPU, where RCCL refuses to run): gloo has no device send/recv,
+            # so the messages go through host copies.  The production backend is "nccl" (= RCCL), device to device.
+            src_dev, dst_dev = src, dst
+            src, dst = src.cpu(), torch.empty(dst.shape, dtype=dst.dtype)
         ops = []
         for (peer, off, cnt, _g) in self.recv_slabs:          # recv offsets are counted from the start of [owned | halo]
             ops.append(dist.P2POp(dist.irecv, dst[off - nl:off - nl + cnt], peer, group))
         for (peer, off, cnt, _g) in self.send_slabs:
             ops.append(dist.P2POp(dist.isend, src[off:off + cnt], peer, group))
-        return halo, (dist.batch_isend_irecv(ops) if ops else [])
+        reqs = dist.batch_isend_irecv(ops) if ops else []
+        if staged and reqs:
+            reqs = [_StagedRequests(reqs, dst_dev, dst)]
+        return halo, reqs
 
     def exchange(self, psi, group=None):
         """Fill the halo buffer from the owning ranks' copies of psi (collective over all ranks)."""

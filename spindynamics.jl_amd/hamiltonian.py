@@ -114,6 +114,31 @@ def Sz_q_vector(model, psi0, q):
     return phi
 
 
+_SPIN_OPS = {"z": 0, "plus": 1, "minus": 2, "x": 3, "y": 4}
+
+
+def create_spin_operator(site, op_type):
+    """create_spin_operator(site, op_type) -- src/Hamiltonian.jl:49-136.  Returns operator(psi, model) -> new vector.
+    op_type is "z", "plus", "minus", "x" or "y" (a leading ':' as in Julia symbols is accepted)."""
+    if int(site) < 1:
+        raise ArgumentError("site must be at least 1")
+    name = str(op_type).lstrip(":")
+    if name not in _SPIN_OPS:
+        raise ArgumentError(f"unsupported spin operator: {op_type}; expected :z, :plus, :minus, :x, or :y")
+    code = _SPIN_OPS[name]
+
+    def operator(psi, model):
+        psi = np.ascontiguousarray(psi)
+        if psi.dtype not in (np.float64, np.complex128):
+            psi = psi.astype(np.complex128 if np.iscomplexobj(psi) else np.float64)
+        out = np.empty_like(psi)
+        check(lib().sd_spin_operator(model.ctx.h, model.h, _dtype_code(psi), int(site), code, psi.ctypes.data, len(psi),
+                                     out.ctypes.data), model.ctx.h)
+        return out
+
+    return operator
+
+
 def cheb_step(phi_next, phi_curr, phi_prev, psi_t, model, a, b, c):
     """One fused Chebyshev term on torch CUDA complex128 tensors
     (src/TimeEvolution/Chebyshev.jl:110-121): phi_next = 2 H~ phi_curr - phi_prev; psi_t += c phi_next."""

@@ -105,3 +105,24 @@ def test_observables_on_device_after_evolution(pkg, O):
     assert abs(mags.sum()) <= 1e-12                         # total S^z = 0 is conserved
     d = pkg.domain_wall_state(m, device="cuda")
     assert d.is_cuda and float(d.sum()) == 1.0 and float(d[0]) == 1.0
+
+
+def test_create_spin_operator_argument_checks_need_no_device(pkg):
+    """src/Hamiltonian.jl:50-55: site and operator name are validated when the closure is created."""
+    with pytest.raises(pkg.ArgumentError):
+        pkg.create_spin_operator(0, "z")
+    with pytest.raises(pkg.ArgumentError):
+        pkg.create_spin_operator(1, "foo")
+    assert callable(pkg.create_spin_operator(3, ":plus"))
+
+
+def test_oracle_spin_operator_known_answers(O):
+    """test/test_Hamiltonian.jl:27-44 on the oracle's scatter form."""
+    r = O.build_model(4, hopping=[(1, 2, 1.0)])
+    psi = np.zeros(16, complex)
+    psi[0] = 1.0
+    assert O.spin_operator(r, 1, "z", psi)[0] == -0.5
+    assert O.spin_operator(r, 1, "plus", psi)[1] == 1.0
+    assert O.spin_operator(r, 1, "x", psi)[1] == 0.5
+    assert O.spin_operator(r, 1, "y", psi)[1] == -0.5j
+    assert np.all(O.spin_operator(r, 1, "minus", psi) == 0)
