@@ -220,6 +220,11 @@ int sd_chebyshev_coeffs(int cheb_n, double a, double b, double dt, double *c_out
  * stream (seed) -- identical on host and device, independent of sharding. */
 int sd_fill_randn_dev(sd_ctx *ctx, void *x_dev, int64_t n_doubles, uint64_t seed, uint64_t first_index);
 int sd_fill_randn_host(double *x, int64_t n_doubles, uint64_t seed, uint64_t first_index);
+/* dot(x, y) = sum conj(x_k) y_k and sum |x_k|^2 over n elements of device vectors (LinearAlgebra.dot / norm^2 as the
+ * recursions use them, e.g. src/Lanczos.jl:40,55,59), reduced in a fixed order (same inputs -> same bits, any n up to
+ * 2^62).  out_re_im[2] / out[1] are host doubles; the call synchronises the stream. */
+int sd_dot_dev(sd_ctx *ctx, int dtype, const void *x_dev, const void *y_dev, int64_t n, double *out_re_im);
+int sd_nrm2sq_dev(sd_ctx *ctx, int dtype, const void *x_dev, int64_t n, double *out);
 
 /* ---- index-range sharding (multi-GPU; one process per GPU) -------------- */
 /* A shard owns the contiguous basis-index range [row_lo, row_hi) (aligned to

@@ -96,6 +96,8 @@ PROTOTYPES = {
     "sd_structure_factor": (_i, [_vp, _vp, _i, _vp, _i64, _dp, _dp]),
     "sd_structure_factor_dev": (_i, [_vp, _vp, _i, _vp, _i64, _dp, _dp]),
     "sd_initial_state_index": (_i, [_vp, _i, _ip, _i, _i64p]),
+    "sd_dot_dev": (_i, [_vp, _i, _vp, _vp, _i64, _dp]),
+    "sd_nrm2sq_dev": (_i, [_vp, _i, _vp, _i64, _dp]),
     "sd_spin_operator": (_i, [_vp, _vp, _i, _i, _i, _vp, _i64, _vp]),
     "sd_symtridiag_eig": (_i, [_i, _dp, _dp, _dp, _dp]),
     "sd_chebyshev_coeffs": (_i, [_i, _d, _d, _d, _dp]),

@@ -561,6 +561,28 @@ int sd_fill_randn_dev(sd_ctx *ctx, void *x, int64_t n, uint64_t seed, uint64_t f
   return sd_k_fill_randn(ctx, (double *)x, n, seed, first);
 }
 
+int sd_dot_dev(sd_ctx *ctx, int dtype, const void *x, const void *y, int64_t n, double *out) {
+  if (!ctx) return SD_EARG;
+  if (!out || n < 0 || (n > 0 && (!x || !y))) return sd_set_err(ctx, SD_EARG, "bad argument");
+  if (dtype != SD_F64 && dtype != SD_C128) return sd_set_err(ctx, SD_EARG, "bad dtype");
+  out[0] = out[1] = 0.0;
+  if (n == 0) return SD_OK;
+  int rc = sd_k_dot(ctx, dtype == SD_C128 ? 2 : 1, (const double *)x, (const double *)y, n, 4);
+  if (rc) return rc;
+  return sd_read_scalars(ctx, 4, dtype == SD_C128 ? 2 : 1, out);
+}
+
+int sd_nrm2sq_dev(sd_ctx *ctx, int dtype, const void *x, int64_t n, double *out) {
+  if (!ctx) return SD_EARG;
+  if (!out || n < 0 || (n > 0 && !x)) return sd_set_err(ctx, SD_EARG, "bad argument");
+  if (dtype != SD_F64 && dtype != SD_C128) return sd_set_err(ctx, SD_EARG, "bad dtype");
+  *out = 0.0;
+  if (n == 0) return SD_OK;
+  int rc = sd_k_nrm2sq(ctx, (const double *)x, n * (dtype == SD_C128 ? 2 : 1), 4);
+  if (rc) return rc;
+  return sd_read_scalars(ctx, 4, 1, out);
+}
+
 int sd_fill_randn_host(double *x, int64_t n, uint64_t seed, uint64_t first) {
   if (!x || n < 0) return SD_EARG;
   for (int64_t i = 0; i < n; ++i) x[i] = sd_randn_host(seed, first + (uint64_t)i);

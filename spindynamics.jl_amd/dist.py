@@ -12,6 +12,8 @@ Two ownership modes (csrc/basis.cpp):
       2.50); the owner packs the requested tiles into a send buffer and ONE message travels per (owner, receiver) pair.
 Transport: torch.distributed P2P ops, i.e. RCCL over xGMI on GPUs (backend "nccl") and gloo in the CPU tests.
 """
+import ctypes as C
+
 from . import _lib
 from ._lib import check, lib
 
@@ -29,11 +31,12 @@ class _StagedRequests:
 
 
 class ShardedOperator:
-    def __init__(self, model, rank, world, exchange_fn=None, mode=None, pack_fn=None):
+    def __init__(self, model, rank, world, exchange_fn=None, mode=None, pack_fn=None, reduce_fn=None):
         self.model = model
         self.rank, self.world = rank, world
         self._exchange_fn = exchange_fn   # tests inject an emulated exchange for virtual shards in one process
         self._pack_fn = pack_fn           # CPU tests inject a numpy pack (the product packs with a HIP kernel)
+        self._reduce_fn = reduce_fn       # CPU tests inject numpy local reductions (the product reduces with HIP kernels)
         model.set_shard(rank, world, mode)
         info = model.shard_info()
         self.mode = "class" if int(info.mode) == 1 else "range"
@@ -198,8 +201,16 @@ class ShardedOperator:
     def dot(self, x, y, group=None):
         """<x|y> over all ranks (conjugate-linear in x)."""
         import torch
-        v = torch.vdot(x, y) if self.n_local else torch.zeros((), dtype=x.dtype, device=x.device)
-        re, im = self._allreduce([v.real.item(), v.imag.item() if v.is_complex() else 0.0], x.device, group)
+        loc = (C.c_double * 2)(0.0, 0.0)
+        if self._reduce_fn is not None:
+            v = complex(self._reduce_fn("dot", x, y))
+            loc[0], loc[1] = v.real, v.imag
+        elif self.n_local:
+            m = self.model
+            m.ctx.set_stream(torch.cuda.current_stream(x.device).cuda_stream)
+            code = _lib.SD_C128 if x.is_complex() else _lib.SD_F64
+            check(lib().sd_dot_dev(m.ctx.h, code, x.data_ptr(), y.data_ptr(), self.n_local, loc), m.ctx.h)
+        re, im = self._allreduce([loc[0], loc[1]], x.device, group)
         return complex(re, im)
 
     def Sz_q_vector(self, psi0, q):
@@ -280,8 +291,12 @@ class ShardedOperator:
 
     def norm(self, x, group=None):
         import torch
-        import torch.distributed as dist
-        s = torch.linalg.vector_norm(x) ** 2
-        if self.world > 1:
-            dist.all_reduce(s, op=dist.ReduceOp.SUM, group=group)
-        return float(s.sqrt())
+        loc = C.c_double(0.0)
+        if self._reduce_fn is not None:
+            loc.value = float(self._reduce_fn("nrm2sq", x, None))
+        elif self.n_local:
+            m = self.model
+            m.ctx.set_stream(torch.cuda.current_stream(x.device).cuda_stream)
+            code = _lib.SD_C128 if x.is_complex() else _lib.SD_F64
+            check(lib().sd_nrm2sq_dev(m.ctx.h, code, x.data_ptr(), self.n_local, C.byref(loc)), m.ctx.h)
+        return float(self._allreduce([loc.value], x.device, group)[0]) ** 0.5

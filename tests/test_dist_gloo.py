@@ -36,7 +36,11 @@ def _worker(rank, world, port, L, nup, mode, q):
             for a, b, c in zip(src, dst, ln):
                 buf_[b:b + c] = psi_[a:a + c]
 
-        op = pkg.ShardedOperator(m, rank, world, mode=mode, pack_fn=numpy_pack)
+        def numpy_reduce(kind, x_, y_):                      # stands in for the HIP reductions on CPU
+            x_ = x_.numpy()
+            return np.vdot(x_, y_.numpy()) if kind == "dot" else float(np.vdot(x_, x_).real)
+
+        op = pkg.ShardedOperator(m, rank, world, mode=mode, pack_fn=numpy_pack, reduce_fn=numpy_reduce)
         rng = np.random.default_rng(42)
         psi = rng.standard_normal(m.N) + 1j * rng.standard_normal(m.N)      # same on every rank
         rows = m.local_rows()
@@ -55,6 +59,8 @@ def _worker(rank, world, port, L, nup, mode, q):
                 ok = ok and bool(np.array_equal(gids[lo - op.n_local:lo - op.n_local + cnt], np.arange(grow, grow + cnt)))
         nrm = op.norm(buf)
         ok = ok and abs(nrm - float(np.linalg.norm(psi))) <= 1e-12 * float(np.linalg.norm(psi))
+        d = op.dot(buf, 2j * buf)                          # conjugate-linear in the first argument, summed over ranks
+        ok = bool(ok and abs(d - 2j * np.vdot(psi, psi)) <= 1e-12 * abs(np.vdot(psi, psi)))
         dist.barrier()
         dist.destroy_process_group()
         q.put((rank, ok, op.n_local, op.n_halo, nrm, float(np.linalg.norm(psi))))

@@ -25,7 +25,7 @@ def closed_form(model, rows, q):
     return bits @ w, bits @ w2
 
 
-@pytest.mark.parametrize("L", [24, 28, 32])
+@pytest.mark.parametrize("L", [24, 28, 32, 34])     # L=34: N = 2.33e9 rows, past 32-bit row indices
 def test_heisenberg_closed_form_full_size(pkg, L):
     import torch
     nup = L // 2
@@ -52,16 +52,19 @@ def test_heisenberg_closed_form_full_size(pkg, L):
     assert np.abs(got_psi - want_psi).max() <= 1e-13          # Sz_q kernel
     assert np.abs(got_out - want_out).max() <= 1e-12          # apply kernel (sum of <= L terms of size <= 1)
     # global checks over all N rows: <psi|H|psi> is real, and equals sum conj(psi) * closed form on the sample ratio
-    e = torch.vdot(psi, out)
-    assert abs(e.imag.item()) <= 1e-9 * abs(e.real.item())
+    vdot = pkg.ShardedOperator(model, 0, 1).dot       # the library's fixed-order reduction (torch.vdot stops at 2^31 elements)
+    e = vdot(psi, out)
+    assert abs(e.imag) <= 1e-9 * abs(e.real)
     # hermiticity with a second, random vector: <x|H psi> == conj(<psi|H x>)
     x = torch.empty_like(psi)
     model.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     pkg.lib().sd_fill_randn_dev(model.ctx.h, x.data_ptr(), 2 * N, 7, 0)
-    lhs = torch.vdot(x, out)
+    lhs = vdot(x, out)
     pkg.apply_H(out, x, model)
-    rhs = torch.vdot(psi, out).conj()
-    assert abs((lhs - rhs).item()) <= 1e-9 * max(1.0, abs(lhs.item()))
+    rhs = vdot(psi, out).conjugate()
+    assert abs(lhs - rhs) <= 1e-9 * max(1.0, abs(lhs))
+    if N < 2 ** 31:
+        assert abs(torch.vdot(psi, out).item() - vdot(psi, out)) <= 1e-9 * max(1.0, abs(lhs))
 
 
 def test_uniform_state_is_exact_eigenvector(pkg):
@@ -72,4 +75,38 @@ def test_uniform_state_is_exact_eigenvector(pkg):
     psi = torch.ones(model.N, dtype=torch.complex128, device="cuda")
     out = torch.empty_like(psi)
     pkg.apply_H(out, psi, model)
+    assert bool((out == (L - 1) / 4).all())
+
+
+@pytest.mark.parametrize("rank", [0, 3, 7])
+def test_config5_shard_of_L36_exact(pkg, rank):
+    """BASELINE config 5 (L=36, nup=18, N = 9.08e9, 8 ranks): one rank's shard at full size on one GPU.  For the uniform
+    state every imported row is 1 too, so the halo can be filled without peers and H|F> = (L-1)/4 |F> must hold bit for
+    bit on every owned row -- through the sharded tile tables, 64-bit global bases and the interior/boundary split."""
+    import torch
+    L, world = 36, 8
+    model = pkg.XXZChain(L, nup=L // 2)
+    assert model.N == 9075135300
+
+    def fill_halo(op, psi, halo):
+        halo.fill_(1.0)
+
+    op = pkg.ShardedOperator(model, rank, world, exchange_fn=fill_halo)
+    free, _ = torch.cuda.mem_get_info()
+    if free < 16 * (2 * op.n_local + op.n_halo) + (4 << 30):
+        pytest.skip("not enough device memory")
+    psi = op.empty(torch.complex128, "cuda")
+    out = op.empty(torch.complex128, "cuda")
+    psi.fill_(1.0)
+    out.zero_()
+    op.apply(out, psi)
+    assert bool((out == (L - 1) / 4).all())
+    # interior tiles alone never touch the halo: poison it and run part 1 + part 2 separately
+    halo = op.halo(psi)
+    halo.fill_(float("nan"))
+    out.zero_()
+    op._launch(out, psi, halo, 0, part=1)
+    assert not bool(torch.isnan(out.real).any())
+    halo.fill_(1.0)
+    op._launch(out, psi, halo, 0, part=2)
     assert bool((out == (L - 1) / 4).all())
