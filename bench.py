@@ -204,7 +204,8 @@ def main():
             "achieved_hbm_GBs_per_gpu": achieved,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_apply_tiled<c128>" if args.dtype == "c128" else "k_apply_tiled<f64>",
+                         "kernel": ("k_apply_tiled<c128>" if args.dtype == "c128" else "k_apply_tiled<f64>")
+                                   + " (one launch per tile length class; all of them timed and counted together)",
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes},
         }
         if world == 1 and not args.no_cpu:

@@ -9,15 +9,17 @@ import os
 import sys
 
 out, L, dtype = sys.argv[1], int(sys.argv[2]), sys.argv[3]
-vals = {"FETCH_SIZE": [], "WRITE_SIZE": []}
+# one apply = one launch of k_apply_tiled per tile length class (different template instantiations = different kernel
+# names): average each instantiation over its dispatches, then add the instantiations up
+vals = {"FETCH_SIZE": {}, "WRITE_SIZE": {}}
 for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
         if "k_apply_tiled" in r["Kernel_Name"] and r["Counter_Name"] in vals:
-            vals[r["Counter_Name"]].append(float(r["Counter_Value"]))
-fetch = sum(vals["FETCH_SIZE"]) / len(vals["FETCH_SIZE"])
-write = sum(vals["WRITE_SIZE"]) / len(vals["WRITE_SIZE"])
+            vals[r["Counter_Name"]].setdefault(r["Kernel_Name"], []).append(float(r["Counter_Value"]))
+fetch = sum(sum(v) / len(v) for v in vals["FETCH_SIZE"].values())
+write = sum(sum(v) / len(v) for v in vals["WRITE_SIZE"].values())
 res = {"L": L, "dtype": dtype, "FETCH_SIZE_KiB_raw": fetch, "WRITE_SIZE_KiB": write,
-       "hbm_bytes_per_launch": (2 * fetch + write) * 1024,
+       "hbm_bytes_per_launch": (2 * fetch + write) * 1024, "launches_per_apply": len(vals["FETCH_SIZE"]),
        "note": "FETCH_SIZE doubled per the gfx950 half-count of wide coalesced reads; Infinity-Cache hits are included "
                "(the counters sit on the L2's fabric side)"}
 json.dump(res, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "traffic_latest.json"), "w"), indent=1)

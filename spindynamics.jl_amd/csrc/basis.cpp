@@ -134,6 +134,87 @@ static int count_nn_hops(const sd_model *m) {
   return L - 1;
 }
 
+// Reorders one launch segment (tp_io, tb_io) in place.  first_seen: 2^p scratch entries, all -1 on entry and on return.
+// XCD-aware processing order.  Workgroups are dealt round-robin over the 8 XCDs (block b -> XCD b % 8), each with
+// a private 4 MiB L2.  A far bond maps tile P onto tile P' = P ^ bond and both read each other.  Tiles related by
+// DISJOINT flippable top bonds (the odd prefix bonds (1,2),(3,4),..: flipping one never changes another) form orbits
+// of 2^f tiles; the members of an orbit are queued back to back on ONE XCD, so that a member's partner reads for
+// those bonds -- the first far bonds it processes, right after its own rows were fetched by the partner -- hit
+// that XCD's L2 (or merge with the in-flight fetch) instead of going to the fabric again.  SD_XCD_ORBIT = max f
+// (0 disables, then SD_XCD_CHUNK consecutive tiles per XCD are used).  Speed only: a bijection of the tile list.
+static void xcd_order(const sd_model *m, int p, std::vector<uint32_t> &tp_io, std::vector<int64_t> &tb_io,
+                      std::vector<int64_t> &first_seen) {
+  {
+    int FO = 6;
+    if (const char *e = getenv("SD_XCD_ORBIT")) FO = atoi(e);
+    if (FO > 8) FO = 8;
+    int CH = 32;
+    if (const char *e = getenv("SD_XCD_CHUNK")) CH = atoi(e);
+    const size_t nt = tp_io.size();
+    auto first_seen_reset = [&](uint32_t P) {
+      uint32_t C0 = P; int ng = 0;
+      for (int b = 1; b + 1 <= p && ng < FO; b += 2)
+        if (((P >> (b - 1)) ^ (P >> b)) & 1u) {
+          if (!((P >> (b - 1)) & 1u)) C0 ^= 3u << (b - 1);
+          ++ng;
+        }
+      first_seen[C0] = -1;
+    };
+    if (FO > 0 && nt >= 64 && p >= 3 && count_nn_hops(m) > 0) {
+      // canonical orbit representative: chosen pairs set to (up, down); member id = which pairs are flipped
+      std::vector<uint64_t> key(nt);     // (first-seen rank of the orbit) << 8 | member id
+      int64_t n_orb = 0;
+      for (size_t k = 0; k < nt; ++k) {
+        const uint32_t P = tp_io[k];
+        uint32_t C0 = P; int member = 0, ng = 0;
+        for (int b = 1; b + 1 <= p && ng < FO; b += 2)
+          if (((P >> (b - 1)) ^ (P >> b)) & 1u) {
+            if (!((P >> (b - 1)) & 1u)) { C0 ^= 3u << (b - 1); member |= 1 << ng; }
+            ++ng;
+          }
+        if (first_seen[C0] < 0) first_seen[C0] = n_orb++;
+        key[k] = ((uint64_t)first_seen[C0] << 8) | (uint64_t)member;
+      }
+      std::vector<size_t> idx(nt);
+      for (size_t k = 0; k < nt; ++k) idx[k] = k;
+      std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return key[a] < key[b]; });
+      // deal whole orbits to the 8 XCD queues, then interleave the queues (position j of queue x -> block 8j + x)
+      std::vector<std::vector<size_t>> q(8);
+      size_t o = 0;
+      size_t OC = 1;   // consecutive orbits handed to the same XCD
+      if (const char *e = getenv("SD_XCD_ORBIT_RUN")) OC = (size_t)std::max(1, atoi(e));
+      for (size_t k = 0; k < nt;) {
+        size_t e = k;
+        while (e < nt && (key[idx[e]] >> 8) == (key[idx[k]] >> 8)) ++e;
+        for (size_t t = k; t < e; ++t) q[(o / OC) % 8].push_back(idx[t]);
+        ++o; k = e;
+      }
+      std::vector<uint32_t> tp; std::vector<int64_t> tb;
+      tp.reserve(nt); tb.reserve(nt);
+      size_t longest = 0;
+      for (auto &v : q) longest = std::max(longest, v.size());
+      for (size_t j = 0; j < longest; ++j)
+        for (int x = 0; x < 8; ++x)
+          if (j < q[x].size()) { tp.push_back(tp_io[q[x][j]]); tb.push_back(tb_io[q[x][j]]); }
+      for (size_t k = 0; k < nt; ++k) first_seen_reset(tp_io[k]);
+      tp_io.swap(tp); tb_io.swap(tb);
+    } else if (CH > 0 && nt >= (size_t)16 * CH) {
+      std::vector<uint32_t> tp(nt);
+      std::vector<int64_t> tb(nt);
+      const size_t group = (size_t)8 * CH, full = nt / group * group;
+      for (size_t b = 0; b < nt; ++b) {
+        size_t t = b;
+        if (b < full) {
+          const size_t x = b % 8, sl = b / 8, g = sl / CH, i = sl % CH;
+          t = g * group + x * CH + i;
+        }
+        tp[b] = tp_io[t]; tb[b] = tb_io[t];
+      }
+      tp_io.swap(tp); tb_io.swap(tb);
+    }
+  }
+}
+
 int sd_build_plan(sd_model *m, int rank, int nranks, std::string &err) {
   if (nranks < 1 || rank < 0 || rank >= nranks) { err = "bad shard rank/nranks"; return SD_EARG; }
   m->rank = rank; m->nranks = nranks;
@@ -264,73 +345,8 @@ int sd_build_plan(sd_model *m, int rank, int nranks, std::string &err) {
   }
   if (m->row_lo < 0) m->row_lo = 0;
 
-  // XCD-aware processing order.  Workgroups are dealt round-robin over the 8 XCDs (block b -> XCD b % 8), each with
-  // a private 4 MiB L2.  A far bond maps tile P onto tile P' = P ^ bond and both read each other.  Tiles related by
-  // DISJOINT flippable top bonds (the odd prefix bonds (1,2),(3,4),..: flipping one never changes another) form orbits
-  // of 2^f tiles; the members of an orbit are queued back to back on ONE XCD, so that a member's partner reads for
-  // those bonds -- the first far bonds it processes, right after its own rows were fetched by the partner -- hit
-  // that XCD's L2 (or merge with the in-flight fetch) instead of going to the fabric again.  SD_XCD_ORBIT = max f
-  // (0 disables, then SD_XCD_CHUNK consecutive tiles per XCD are used).  Speed only: a bijection of the tile list.
-  {
-    int FO = 6;
-    if (const char *e = getenv("SD_XCD_ORBIT")) FO = atoi(e);
-    if (FO > 8) FO = 8;
-    int CH = 32;
-    if (const char *e = getenv("SD_XCD_CHUNK")) CH = atoi(e);
-    const size_t nt = m->tile_prefix.size();
-    if (FO > 0 && nt >= 64 && p >= 3 && count_nn_hops(m) > 0) {
-      // canonical orbit representative: chosen pairs set to (up, down); member id = which pairs are flipped
-      std::vector<uint64_t> key(nt);     // (first-seen rank of the orbit) << 8 | member id
-      std::vector<int64_t> first_seen((size_t)1 << p, -1);
-      int64_t n_orb = 0;
-      for (size_t k = 0; k < nt; ++k) {
-        const uint32_t P = m->tile_prefix[k];
-        uint32_t C0 = P; int member = 0, ng = 0;
-        for (int b = 1; b + 1 <= p && ng < FO; b += 2)
-          if (((P >> (b - 1)) ^ (P >> b)) & 1u) {
-            if (!((P >> (b - 1)) & 1u)) { C0 ^= 3u << (b - 1); member |= 1 << ng; }
-            ++ng;
-          }
-        if (first_seen[C0] < 0) first_seen[C0] = n_orb++;
-        key[k] = ((uint64_t)first_seen[C0] << 8) | (uint64_t)member;
-      }
-      std::vector<size_t> idx(nt);
-      for (size_t k = 0; k < nt; ++k) idx[k] = k;
-      std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return key[a] < key[b]; });
-      // deal whole orbits to the 8 XCD queues, then interleave the queues (position j of queue x -> block 8j + x)
-      std::vector<std::vector<size_t>> q(8);
-      size_t o = 0;
-      size_t OC = 1;   // consecutive orbits handed to the same XCD
-      if (const char *e = getenv("SD_XCD_ORBIT_RUN")) OC = (size_t)std::max(1, atoi(e));
-      for (size_t k = 0; k < nt;) {
-        size_t e = k;
-        while (e < nt && (key[idx[e]] >> 8) == (key[idx[k]] >> 8)) ++e;
-        for (size_t t = k; t < e; ++t) q[(o / OC) % 8].push_back(idx[t]);
-        ++o; k = e;
-      }
-      std::vector<uint32_t> tp; std::vector<int64_t> tb;
-      tp.reserve(nt); tb.reserve(nt);
-      size_t longest = 0;
-      for (auto &v : q) longest = std::max(longest, v.size());
-      for (size_t j = 0; j < longest; ++j)
-        for (int x = 0; x < 8; ++x)
-          if (j < q[x].size()) { tp.push_back(m->tile_prefix[q[x][j]]); tb.push_back(m->tile_base[q[x][j]]); }
-      m->tile_prefix.swap(tp); m->tile_base.swap(tb);
-    } else if (CH > 0 && nt >= (size_t)16 * CH) {
-      std::vector<uint32_t> tp(nt);
-      std::vector<int64_t> tb(nt);
-      const size_t group = (size_t)8 * CH, full = nt / group * group;
-      for (size_t b = 0; b < nt; ++b) {
-        size_t t = b;
-        if (b < full) {
-          const size_t x = b % 8, sl = b / 8, g = sl / CH, i = sl % CH;
-          t = g * group + x * CH + i;
-        }
-        tp[b] = m->tile_prefix[t]; tb[b] = m->tile_base[t];
-      }
-      m->tile_prefix.swap(tp); m->tile_base.swap(tb);
-    }
-  }
+  std::vector<int64_t> xcd_scratch((size_t)1 << p, -1);
+  xcd_order(m, p, m->tile_prefix, m->tile_base, xcd_scratch);
 
   // Grouping (single-GPU NN-chain plans).  Candidate generators are the odd prefix bonds (1,2),(3,4),... : they are
   // pairwise disjoint, so flipping one never changes whether another is flippable.  A tile whose first three flippable
@@ -418,35 +434,64 @@ int sd_build_plan(sd_model *m, int rank, int nranks, std::string &err) {
       if (q == rank) m->n_halo = halo_off - m->n_local;
     }
   }
-  // interior tiles (every hop partner owned) first: they can run while the halo exchange is still in flight
-  m->n_interior = (int)m->single_prefix.size();
-  if (nranks > 1 && m->n_halo > 0) {
-    const int nn = count_nn_hops(m);
-    auto remote = [&](uint32_t Q) { return Q < nP && m->addr[Q] >= m->n_local; };
-    std::vector<uint8_t> boundary(m->single_prefix.size(), 0);
-    for (size_t k = 0; k < m->single_prefix.size(); ++k) {
-      const uint32_t P = m->single_prefix[k];
-      bool bd = false;
-      if (nn > 0) {
-        for (int b = 1; b <= p - 1 && !bd; ++b)
-          if ((((P >> (b - 1)) ^ (P >> b)) & 1u) && remote(P ^ (3u << (b - 1)))) bd = true;
-        if (!bd && p >= 1 && remote(P ^ (1u << (p - 1)))) bd = true;
+  // Launch segments of the single tiles: (interior | boundary) x (length class).  Interior tiles (every hop partner owned)
+  // come first: they can run while the halo exchange is still in flight.  Inside each part the tiles are split by the
+  // smallest workgroup (64..1024 threads x 4 rows) that covers them, one launch per class: a 220-row tile in a 256-thread
+  // workgroup leaves three waves idle and costs about as much as 300 extra rows; in a one-wave workgroup four times as
+  // many such tiles are in flight per CU.  Each segment is XCD-ordered on its own (block index restarts per launch).
+  // SD_LEN_CLASSES=0 keeps one class.  Order only: results do not depend on it (except the order of partial sums).
+  {
+    const size_t ns = m->single_prefix.size();
+    std::vector<uint8_t> boundary(ns, 0);
+    if (nranks > 1 && m->n_halo > 0) {
+      const int nn = count_nn_hops(m);
+      auto remote = [&](uint32_t Q) { return Q < nP && m->addr[Q] >= m->n_local; };
+      for (size_t k = 0; k < ns; ++k) {
+        const uint32_t P = m->single_prefix[k];
+        bool bd = false;
+        if (nn > 0) {
+          for (int b = 1; b <= p - 1 && !bd; ++b)
+            if ((((P >> (b - 1)) ^ (P >> b)) & 1u) && remote(P ^ (3u << (b - 1)))) bd = true;
+          if (!bd && p >= 1 && remote(P ^ (1u << (p - 1)))) bd = true;
+        }
+        for (size_t h = (size_t)nn; h < m->hop_i.size() && !bd; ++h) {
+          const int i = m->hop_i[h], j = m->hop_j[h];
+          uint32_t Q = P;
+          if (i <= p) Q ^= 1u << (i - 1);
+          if (j <= p) Q ^= 1u << (j - 1);
+          if (Q != P && remote(Q)) bd = true;
+        }
+        boundary[k] = bd;
       }
-      for (size_t h = (size_t)nn; h < m->hop_i.size() && !bd; ++h) {
-        const int i = m->hop_i[h], j = m->hop_j[h];
-        uint32_t Q = P;
-        if (i <= p) Q ^= 1u << (i - 1);
-        if (j <= p) Q ^= 1u << (j - 1);
-        if (Q != P && remote(Q)) bd = true;
-      }
-      boundary[k] = bd;
     }
-    std::vector<uint32_t> sp; std::vector<int64_t> sb;
-    for (int pass = 0; pass < 2; ++pass)
-      for (size_t k = 0; k < boundary.size(); ++k)
-        if (boundary[k] == pass) { sp.push_back(m->single_prefix[k]); sb.push_back(m->single_base[k]); }
-    m->n_interior = (int)std::count(boundary.begin(), boundary.end(), (uint8_t)0);
-    m->single_prefix.swap(sp); m->single_base.swap(sb);
+    bool split = ns >= 4096;
+    if (const char *e = getenv("SD_LEN_CLASSES")) split = split && atoi(e) != 0;
+    int top = 0;                                     // class of the longest tile: the only class when not splitting
+    while (top < SD_N_LEN_CLASS - 1 && (64 << top) * 4 < m->max_tile_len) ++top;
+    auto cls_of = [&](uint32_t P) {
+      if (!split) return top;
+      const int64_t len = B(m, m->LS, m->nup - __builtin_popcount(P));
+      int c = 0;
+      while (c < top && (64 << c) * 4 < len) ++c;
+      return c;
+    };
+    std::vector<std::vector<uint32_t>> sp(2 * SD_N_LEN_CLASS);
+    std::vector<std::vector<int64_t>> sb(2 * SD_N_LEN_CLASS);
+    for (size_t k = 0; k < ns; ++k) {
+      // longest class first: the short-tile launches fill the tail of the long one
+      const int sgi = boundary[k] * SD_N_LEN_CLASS + (SD_N_LEN_CLASS - 1 - cls_of(m->single_prefix[k]));
+      sp[sgi].push_back(m->single_prefix[k]); sb[sgi].push_back(m->single_base[k]);
+    }
+    m->single_prefix.clear(); m->single_base.clear();
+    for (int sgi = 0; sgi < 2 * SD_N_LEN_CLASS; ++sgi) {
+      m->seg_off[sgi] = (int)m->single_prefix.size();
+      m->seg_cls[sgi] = SD_N_LEN_CLASS - 1 - sgi % SD_N_LEN_CLASS;
+      if (split || (nranks > 1 && m->n_halo > 0)) xcd_order(m, p, sp[sgi], sb[sgi], xcd_scratch);   // else: already in XCD order
+      m->single_prefix.insert(m->single_prefix.end(), sp[sgi].begin(), sp[sgi].end());
+      m->single_base.insert(m->single_base.end(), sb[sgi].begin(), sb[sgi].end());
+    }
+    m->seg_off[2 * SD_N_LEN_CLASS] = (int)m->single_prefix.size();
+    m->n_interior = m->seg_off[SD_N_LEN_CLASS];
   }
   m->tile_gbase.resize(m->tile_prefix.size());
   for (size_t k = 0; k < m->tile_prefix.size(); ++k) m->tile_gbase[k] = tile_base_global(m, m->tile_prefix[k]);

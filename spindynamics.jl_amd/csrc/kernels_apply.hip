@@ -503,14 +503,19 @@ int launch_tiled_cfg(sd_ctx *ctx, const sd_dev_model &dm, int nt, size_t shmem, 
 }
 
 template <int NC, bool FMA>
-int launch_tiled(sd_ctx *ctx, const sd_dev_model &dm, int nt, size_t shmem, double *out, const double *psi, int epi,
+int launch_tiled(sd_ctx *ctx, const sd_dev_model &dm, int nt, int cls, size_t shmem, double *out, const double *psi, int epi,
                  const sd_epi_args &ea, int max_len) {
-  // 4 rows per thread; smallest block that covers the longest tile
+  // 4 rows per thread; cls selects the workgroup size (64 << cls threads) that covers the segment's longest tile
   constexpr int R = 4;
-  if (max_len <= 256 * R) return launch_tiled_cfg<NC, R, 256, FMA>(ctx, dm, nt, shmem, out, psi, epi, ea, max_len);
-  if (max_len <= 512 * R) return launch_tiled_cfg<NC, R, 512, FMA>(ctx, dm, nt, shmem, out, psi, epi, ea, max_len);
-  if (max_len <= 1024 * R) return launch_tiled_cfg<NC, R, 1024, FMA>(ctx, dm, nt, shmem, out, psi, epi, ea, max_len);
-  return sd_set_err(ctx, SD_EINTERNAL, "tile longer than a workgroup can hold");
+  if ((64 << cls) * R < max_len) return sd_set_err(ctx, SD_EINTERNAL, "tile longer than its workgroup can hold");
+  switch (cls) {
+    case 0: return launch_tiled_cfg<NC, R, 64, FMA>(ctx, dm, nt, shmem, out, psi, epi, ea, max_len);
+    case 1: return launch_tiled_cfg<NC, R, 128, FMA>(ctx, dm, nt, shmem, out, psi, epi, ea, max_len);
+    case 2: return launch_tiled_cfg<NC, R, 256, FMA>(ctx, dm, nt, shmem, out, psi, epi, ea, max_len);
+    case 3: return launch_tiled_cfg<NC, R, 512, FMA>(ctx, dm, nt, shmem, out, psi, epi, ea, max_len);
+    case 4: return launch_tiled_cfg<NC, R, 1024, FMA>(ctx, dm, nt, shmem, out, psi, epi, ea, max_len);
+  }
+  return sd_set_err(ctx, SD_EINTERNAL, "bad tile length class");
 }
 
 }  // namespace
@@ -527,7 +532,7 @@ int sd_launch_apply(sd_ctx *ctx, const sd_model *m, int dtype, void *out, const 
     int nt = dm.n_singles;
     const int ng = part == 0 ? dm.n_groups : 0;
     if (part == 1) nt = dm.n_interior;
-    else if (part == 2) { dm.tile_off = dm.n_interior; nt = dm.n_singles - dm.n_interior; }
+    else if (part == 2) nt = dm.n_singles - dm.n_interior;
     if (sums) { int rc = sd_ensure_partials(ctx, 2 * (size_t)(nt + ng)); if (rc) return rc; }
     const int max_len = m->max_tile_len;
     const size_t esz = dtype == SD_C128 ? 16 : 8;
@@ -548,15 +553,24 @@ int sd_launch_apply(sd_ctx *ctx, const sd_model *m, int dtype, void *out, const 
       SD_HIP(ctx, hipGetLastError());
     }
     if (nt > 0) {
-      const size_t shmem = (size_t)(max_len + 1) * esz + 16 * SD_BIN_STRIDE * sizeof(int) + 32 * sizeof(double) + 16;
       double *saved = ctx->d_partials;
       ctx->d_partials = saved ? saved + 2 * (size_t)ng : saved;      // singles write their partials after the groups'
-      if (dtype == SD_C128)
-        rc = m->hop_pow2 ? launch_tiled<2, true>(ctx, dm, nt, shmem, (double *)out, (const double *)psi, epi, ea, max_len)
-                         : launch_tiled<2, false>(ctx, dm, nt, shmem, (double *)out, (const double *)psi, epi, ea, max_len);
-      else
-        rc = m->hop_pow2 ? launch_tiled<1, true>(ctx, dm, nt, shmem, (double *)out, (const double *)psi, epi, ea, max_len)
-                         : launch_tiled<1, false>(ctx, dm, nt, shmem, (double *)out, (const double *)psi, epi, ea, max_len);
+      // one launch per non-empty (part, tile length class) segment; a segment's LDS image is sized by its own longest tile
+      const int s0 = part == 2 ? SD_N_LEN_CLASS : 0, s1 = part == 1 ? SD_N_LEN_CLASS : 2 * SD_N_LEN_CLASS;
+      for (int sg = s0; sg < s1 && rc == SD_OK; ++sg) {
+        const int cnt = m->seg_off[sg + 1] - m->seg_off[sg];
+        if (cnt <= 0) continue;
+        const int cls = m->seg_cls[sg];
+        const int seg_max = std::min(max_len, (64 << cls) * 4);
+        const size_t shmem = (size_t)(seg_max + 1) * esz + 16 * SD_BIN_STRIDE * sizeof(int) + 32 * sizeof(double) + 16;
+        dm.tile_off = m->seg_off[sg];
+        if (dtype == SD_C128)
+          rc = m->hop_pow2 ? launch_tiled<2, true>(ctx, dm, cnt, cls, shmem, (double *)out, (const double *)psi, epi, ea, seg_max)
+                           : launch_tiled<2, false>(ctx, dm, cnt, cls, shmem, (double *)out, (const double *)psi, epi, ea, seg_max);
+        else
+          rc = m->hop_pow2 ? launch_tiled<1, true>(ctx, dm, cnt, cls, shmem, (double *)out, (const double *)psi, epi, ea, seg_max)
+                           : launch_tiled<1, false>(ctx, dm, cnt, cls, shmem, (double *)out, (const double *)psi, epi, ea, seg_max);
+      }
       ctx->d_partials = saved;
       if (rc) return rc;
     }

@@ -97,6 +97,8 @@ struct sd_dev_model {
   unsigned long long *stamps;    // diagnostic builds only (sd_debug_phase_profile): 8 s_memtime stamps per tile, else null
 };
 
+#define SD_N_LEN_CLASS 5   // tile length classes: workgroups of 64, 128, 256, 512, 1024 threads (x 4 rows)
+
 struct sd_model {
   sd_ctx *ctx = nullptr;  // may be null (host-only model)
   int L = 0, nup = -1;
@@ -122,6 +124,8 @@ struct sd_model {
   std::vector<uint32_t> group_P0, group_gens;  // grouped tiles (unsharded NN-chain plans only)
   std::vector<uint32_t> single_prefix;
   int n_interior = 0;
+  int seg_off[2 * SD_N_LEN_CLASS + 1] = {0};   // launch segments of the single tiles: (interior | boundary) x length class
+  int seg_cls[2 * SD_N_LEN_CLASS] = {0};       // workgroup size of a segment's kernel = 64 << seg_cls
   int group_ngen = 0;          // generator bonds per group (2 or 3)
   std::vector<int64_t> single_base;
   std::vector<sd_tile_rec> single_rec;
