@@ -231,9 +231,11 @@ int sd_build_plan(sd_model *m, int rank, int nranks, std::string &err) {
     if (nranks != 1) { err = "sharding needs a fixed-nup sector with at most 2^26 prefix tiles"; return SD_EARG; }
     m->p = -1; m->LS = 0;
     m->row_lo = 0; m->row_hi = m->N; m->n_local = m->N;
+    // full 2^L basis: idx = state, so 2^10 consecutive rows form a tile without any table (k_apply_fulltile)
+    m->full_ls = (m->nup < 0 && L >= 12 && L <= 40 && !getenv("SD_NO_FULLTILE")) ? 10 : 0;
     return SD_OK;
   }
-  m->p = p; m->LS = LS;
+  m->p = p; m->LS = LS; m->full_ls = 0;
 
   // suffix sector tables
   m->suf_off.assign(LS + 2, 0);
@@ -439,7 +441,7 @@ int sd_build_plan(sd_model *m, int rank, int nranks, std::string &err) {
   // smallest workgroup (64..1024 threads x 4 rows) that covers them, one launch per class: a 220-row tile in a 256-thread
   // workgroup leaves three waves idle and costs about as much as 300 extra rows; in a one-wave workgroup four times as
   // many such tiles are in flight per CU.  Each segment is XCD-ordered on its own (block index restarts per launch).
-  // SD_LEN_CLASSES=0 keeps one class.  Order only: results do not depend on it (except the order of partial sums).
+  // SD_LEN_CLASSES=0 keeps one class, =2 splits small plans too (tests).  Order only: results do not depend on it (except the order of partial sums).
   {
     const size_t ns = m->single_prefix.size();
     std::vector<uint8_t> boundary(ns, 0);
@@ -465,7 +467,7 @@ int sd_build_plan(sd_model *m, int rank, int nranks, std::string &err) {
       }
     }
     bool split = ns >= 4096;
-    if (const char *e = getenv("SD_LEN_CLASSES")) split = split && atoi(e) != 0;
+    if (const char *e = getenv("SD_LEN_CLASSES")) split = atoi(e) >= 2 || (split && atoi(e) != 0);   // 2: also for small plans
     int top = 0;                                     // class of the longest tile: the only class when not splitting
     while (top < SD_N_LEN_CLASS - 1 && (64 << top) * 4 < m->max_tile_len) ++top;
     auto cls_of = [&](uint32_t P) {
@@ -534,7 +536,8 @@ int sd_upload_model(sd_model *m, std::string &err) {
   d.L = m->L; d.nup = m->nup; d.p = m->p; d.LS = m->LS;
   d.n_hop = (int)m->hop_i.size(); d.n_zz = (int)m->zz_i.size();
   d.N = m->N; d.n_local = m->n_local; d.row_lo = m->row_lo;
-  d.nn_hops = (m->p >= 0) ? count_nn_hops(m) : 0;
+  d.full_ls = m->full_ls;
+  d.nn_hops = (m->p >= 0 || m->full_ls > 0) ? count_nn_hops(m) : 0;
   d.field_zero = 1;
   for (double h : m->field) if (h != 0.0) d.field_zero = 0;
   // closed-form diagonal when it is bit-identical to the reference's sequential sum

@@ -442,6 +442,146 @@ __global__ __launch_bounds__(128 << NGEN, 4) void k_apply_grouped(sd_dev_model d
 }
 
 // =====================================================================
+// full-basis tiled kernel (nup = nothing: idx = state, src/Hamiltonian.jl:223,255-257)
+// =====================================================================
+//
+// Site i is bit i-1 of the row index, so 2^LF consecutive rows form a tile without any table: sites 1..LF vary inside
+// the tile, sites LF+1..L are the tile number T.  A hop on the chain bond (a, a+1) flips two index bits:
+//   a+1 <= LF : partner row i ^ (3 << (a-1)) of the same tile                              -> LDS
+//   a   == LF : the half of the tile whose bit LF-1 differs from T's bit 0 reads the other half of tile T ^ 1
+//   a   >  LF : whole tile T ^ (3 << (a-LF-1)) at the same in-tile offset (when T's two bits differ)
+// Accumulation per row is the reference's bond order 1..L-1: the LDS bonds first, then the streams (requested before the
+// LDS phase, consumed after it), then any further bonds of the hop list as gathers.
+template <int NC, bool FMA>
+__global__ __launch_bounds__(256, 4) void k_apply_fulltile(sd_dev_model dm, double *__restrict__ out_,
+                                                        const double *__restrict__ psi_, int epi, sd_epi_args ea,
+                                                        double *__restrict__ partials) {
+  using V = typename VT<NC>::type;
+  constexpr uint32_t ES = sizeof(V);
+  constexpr int R = 4, BLOCK = 256;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int LF = dm.full_ls, TL = 1 << LF;            // TL == R * BLOCK
+  V *tile = reinterpret_cast<V *>(smem);               // TL rows + one all-zero row at index TL
+  double *red = reinterpret_cast<double *>(smem + (size_t)(TL + 1) * sizeof(V));
+  const V *__restrict__ psi = reinterpret_cast<const V *>(psi_);
+  const int tid = threadIdx.x, lane = tid & 63;
+  // blocks are dealt round-robin to the 8 XCDs: hand each XCD runs of 32 consecutive tiles (neighbouring tiles are partners)
+  uint32_t T = blockIdx.x;
+  if (gridDim.x >= 512 && (gridDim.x & 255u) == 0) {
+    const uint32_t x = T & 7u, j = T >> 3, g = j >> 5, i = j & 31u;
+    T = (g << 8) + (x << 5) + i;
+  }
+  const int64_t base = (int64_t)T << LF;
+  const int nn = dm.nn_hops;
+
+  V own[R];
+  uint32_t ioff[R];
+  {
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(psi + base, (uint32_t)TL * ES);
+#pragma unroll
+    for (int r = 0; r < R; ++r) { ioff[r] = (uint32_t)(tid + r * BLOCK) * ES; buf_load(own[r], rs, ioff[r]); }
+  }
+  // per-wave list of flippable stream bonds: lane 0 <-> bond LF (straddle), lane k <-> bond LF + k
+  uint64_t fmask = 0;
+  int64_t my_base = 0;
+  double my_J = 0.0;
+  int my_lo = 0, my_n = TL;
+  if (nn > 0) {
+    const int a = LF + lane;
+    bool fl = false;
+    if (a <= dm.L - 1) {
+      if (lane == 0) {
+        const int t = (int)(T & 1u);
+        my_lo = (1 - t) * (TL / 2); my_n = TL / 2;
+        my_base = ((int64_t)(T ^ 1u) << LF) + (TL / 2 - my_lo);
+        fl = true;
+      } else {
+        const int b = a - LF - 1;
+        fl = ((T >> b) ^ (T >> (b + 1))) & 1u;
+        my_base = (int64_t)(T ^ (3u << b)) << LF;
+      }
+      my_J = dm.hop_J[a - 1];
+    }
+    fmask = __ballot(fl);
+  }
+  auto get_bond = [&](int ln) {
+    FarBond fb;
+    fb.base = rl64(my_base, ln); fb.J = rld(my_J, ln);
+    fb.lo = rl(my_lo, ln); fb.n = rl(my_n, ln);
+    return fb;
+  };
+  auto issue = [&](const FarBond &fb, V(&v)[R]) {
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(psi + fb.base, (uint32_t)fb.n * ES);
+    const uint32_t lo_b = (uint32_t)fb.lo * ES;
+#pragma unroll
+    for (int r = 0; r < R; ++r) buf_load(v[r], rs, ioff[r] - lo_b);
+  };
+  V va[R], vb[R];
+  FarBond fa{}, fbb{};
+  uint64_t mk = fmask;
+  bool have_a = false;
+  auto next_lane = [&](uint64_t &m_) { const int ln = __builtin_ctzll(m_); m_ &= m_ - 1; return ln; };
+  if (mk) { fa = get_bond(next_lane(mk)); issue(fa, va); have_a = true; }
+
+  V acc[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    acc[r] = vscale(diag_of(dm, (uint64_t)base + (uint64_t)(tid + r * BLOCK)), own[r]);
+    tile[tid + r * BLOCK] = own[r];
+  }
+  if (tid == 0) tile[TL] = V{};
+  __syncthreads();
+
+  // bonds inside the tile (LDS)
+  const int n_in = nn > 0 ? LF - 1 : 0;
+  for (int a = 1; a <= n_in; ++a) {
+    const double J = dm.hop_J[a - 1];
+    V v[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int i = tid + r * BLOCK;
+      const bool fl = ((i >> (a - 1)) ^ (i >> a)) & 1;
+      v[r] = tile[fl ? (i ^ (3 << (a - 1))) : TL];
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = accum<FMA>(acc[r], J, v[r]);
+  }
+  // streams, ascending bond order
+  while (have_a) {
+    bool have_b = false;
+    if (mk) { fbb = get_bond(next_lane(mk)); issue(fbb, vb); have_b = true; }
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = accum<FMA>(acc[r], fa.J, va[r]);
+    have_a = false;
+    if (!have_b) break;
+    if (mk) { fa = get_bond(next_lane(mk)); issue(fa, va); have_a = true; }
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = accum<FMA>(acc[r], fbb.J, vb[r]);
+  }
+  // remaining (general) bonds: idx' = idx ^ (two bits)
+  for (int h = nn; h < dm.n_hop; ++h) {
+    const int bi = dm.hop_i[h] - 1, bj = dm.hop_j[h] - 1;
+    const double J = dm.hop_J[h];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const uint64_t s = (uint64_t)base + (uint64_t)(tid + r * BLOCK);
+      if (((s >> bi) ^ (s >> bj)) & 1) acc[r] = accum<false>(acc[r], J, psi[s ^ ((uint64_t)1 << bi) ^ ((uint64_t)1 << bj)]);
+    }
+  }
+  EpiSums sums{0.0, 0.0};
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int i = tid + r * BLOCK;
+    epilogue<NC>(epi, ea, base + i, acc[r], tile[i], out_, sums);
+  }
+  if (epi_has_sums(epi)) {
+    double a = sums.s0, b = sums.s1;
+    block_reduce2(a, b, red);
+    if (tid == 0) { partials[2 * (size_t)blockIdx.x] = a; partials[2 * (size_t)blockIdx.x + 1] = b; }
+  }
+}
+
+// =====================================================================
 // generic kernel: one row per thread, grid-stride
 // =====================================================================
 template <int NC>
@@ -576,6 +716,21 @@ int sd_launch_apply(sd_ctx *ctx, const sd_model *m, int dtype, void *out, const 
     }
     if (sums) {
       hipLaunchKernelGGL(k_reduce_pairs, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_partials, (int64_t)(nt + ng), ctx->d_scalars);
+      SD_HIP(ctx, hipGetLastError());
+    }
+  } else if (m->full_ls > 0) {
+    const int64_t nb = dm.N >> m->full_ls;
+    if (sums) { int rc = sd_ensure_partials(ctx, 2 * (size_t)nb); if (rc) return rc; }
+    const size_t esz = dtype == SD_C128 ? 16 : 8;
+    const size_t shmem = (((size_t)1 << m->full_ls) + 1) * esz + 32 * sizeof(double) + 16;
+    void (*kf)(sd_dev_model, double *, const double *, int, sd_epi_args, double *) =
+        dtype == SD_C128 ? (m->hop_pow2 ? k_apply_fulltile<2, true> : k_apply_fulltile<2, false>)
+                         : (m->hop_pow2 ? k_apply_fulltile<1, true> : k_apply_fulltile<1, false>);
+    hipLaunchKernelGGL(kf, dim3((unsigned)nb), dim3(256), shmem, ctx->stream, dm, (double *)out, (const double *)psi, epi, ea,
+                       ctx->d_partials);
+    SD_HIP(ctx, hipGetLastError());
+    if (sums) {
+      hipLaunchKernelGGL(k_reduce_pairs, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_partials, nb, ctx->d_scalars);
       SD_HIP(ctx, hipGetLastError());
     }
   } else {

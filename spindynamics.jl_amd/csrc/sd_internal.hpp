@@ -58,6 +58,7 @@ struct sd_dev_model {
   int L, nup;            // nup < 0: full basis
   int p, LS;             // prefix / suffix site counts (tiled path); p = -1 when untiled
   int n_hop, n_zz;
+  int full_ls;           // full 2^L basis, tiled path: a tile is 2^full_ls consecutive rows (0: not in use)
   int nn_hops;           // leading hops that are exactly (1,2),(2,3),...,(L-1,L) in order (L-1 or 0)
   int diag_mode;         // 0 exact list order, 1 uniform closed form
   double diag_q;         // Jz/4 for diag_mode 1
@@ -108,6 +109,7 @@ struct sd_model {
   std::vector<int64_t> binom;  // host copy
   // plan
   int p = -1, LS = 0;
+  int full_ls = 0;             // full-basis tiled path (nup < 0, L >= 12, unsharded): log2 rows per tile
   int rank = 0, nranks = 1;
   int64_t row_lo = 0, row_hi = 0, n_local = 0, n_halo = 0;
   std::vector<uint32_t> tile_prefix;  // local tiles

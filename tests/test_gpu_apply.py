@@ -35,6 +35,11 @@ CASES = [
     (21, 10, 1.0, 1.0, 0.0, "periodic"),
     (10, None, 1.0, 1.0, 0.0, "open"),
     (11, None, 0.8, 1.2, 0.1, "periodic"),
+    # full 2^L basis, L >= 12: k_apply_fulltile (tiles of 2^10 consecutive rows)
+    (12, None, 1.0, 1.0, 0.0, "open"),
+    (13, None, 0.8, 1.2, 0.1, "periodic"),
+    (15, None, 1.0, 0.4, -0.3, "open"),
+    (19, None, 1.0, 1.0, 0.0, "open"),        # >= 512 tiles: XCD-chunked tile order
 ]
 
 
@@ -105,6 +110,58 @@ def test_dimension_and_argument_errors(pkg):
         pkg.XXZChain(64, nup=1)
     with pytest.raises(pkg.ArgumentError):
         pkg.XXZChain(6, nup=3, boundary="twisted")
+
+
+@pytest.mark.parametrize("ls", ["11", "12", "13"])
+def test_tile_length_classes_bit_exact(pkg, O, ls, monkeypatch):
+    """Plans with >= 4096 tiles launch one kernel per tile length class (64/128/256-thread workgroups).  SD_LEN_CLASSES=2
+    forces the split on plans small enough for the oracle: plain, rescaled and the reduction epilogues (KPM moments)."""
+    monkeypatch.setenv("SD_LEN_CLASSES", "2")
+    monkeypatch.setenv("SD_SUFFIX_BITS", ls)
+    for (L, nup, bc) in [(16, 8, "open"), (19, 9, "periodic"), (20, 7, "open")]:
+        m = pkg.XXZChain(L, nup=nup, Jz=0.7, hz=0.1, boundary=bc)
+        r = O.XXZChain(L, nup=nup, Jz=0.7, hz=0.1, boundary=bc)
+        for cplx in (True, False):
+            psi = rand_vec(m.N, 31 + L, cplx)
+            out = np.empty_like(psi)
+            pkg.apply_H(out, psi, m)
+            assert np.array_equal(out, O.apply_H(r, psi))
+        a, b = 7.5, 0.25
+        pkg.apply_rescaled_H(out, psi, pkg.apply_H, m, a, b)
+        assert np.array_equal(out, O.apply_rescaled_H(r, psi, a, b))
+        phi = rand_vec(m.N, 5)
+        phi /= np.linalg.norm(phi)
+        mu = pkg.compute_chebyshev_moments(pkg.apply_H, phi, 12, a, b, m)
+        want = O.compute_chebyshev_moments(r, phi, 12, a, b)
+        assert np.abs(mu - want).max() <= 1e-12            # fixed-order partial sums differ from the oracle's serial sum
+
+
+def test_full_basis_tiled_path(pkg, O):
+    """nup = nothing, L >= 12: general bond lists (long-range hops, fields, zz) and the fused epilogues on the full-basis
+    tiled kernel; leading chain bonds take the LDS / stream path, the rest are gathers -- all in list order, bit-exact."""
+    L = 13
+    assert pkg.XXZChain(L).device_path == "full-tiled"
+    chain = [(i, i + 1, 0.5) for i in range(1, L)]
+    extra = [(1, L, 0.25), (2, 7, -0.3), (3, 12, 0.11)]
+    zz = [(i, i + 1, 0.9) for i in range(1, L)] + [(1, L, 0.4)]
+    f = np.linspace(-0.2, 0.3, L)
+    for hop in (chain + extra, extra + chain, chain):
+        m = pkg.build_model(L, hopping=hop, onsite_field=f, zz=zz)
+        r = O.build_model(L, hopping=hop, onsite_field=f, zz=zz)
+        for cplx in (True, False):
+            psi = rand_vec(m.N, 9, cplx)
+            out = np.empty_like(psi)
+            pkg.apply_H(out, psi, m)
+            assert np.array_equal(out, O.apply_H(r, psi))
+        pkg.apply_rescaled_H(out, psi, pkg.apply_H, m, 6.0, -0.5)
+        assert np.array_equal(out, O.apply_rescaled_H(r, psi, 6.0, -0.5))
+    phi = rand_vec(m.N, 5)
+    phi /= np.linalg.norm(phi)
+    mu = pkg.compute_chebyshev_moments(pkg.apply_H, phi, 10, 6.0, -0.5, m)
+    assert np.abs(mu - O.compute_chebyshev_moments(r, phi, 10, 6.0, -0.5)).max() <= 1e-12
+    E0, psi0 = pkg.groundstate(m, lanc_m=80)                # DOT epilogue inside the Lanczos recursion
+    want = O.apply_H(r, psi0)
+    assert np.linalg.norm(want - E0 * psi0) < 1e-8          # a converged eigenpair of the oracle's operator
 
 
 @pytest.mark.parametrize("gb", ["2", "3"])

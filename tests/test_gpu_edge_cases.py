@@ -24,6 +24,7 @@ def test_small_and_long_chains_bit_exact(pkg, O, L, nup):
 def test_device_paths_reported(pkg):
     assert pkg.XXZChain(12, nup=6).device_path == "tiled"
     assert pkg.XXZChain(8, nup=None).device_path == "generic"
+    assert pkg.XXZChain(14, nup=None).device_path == "full-tiled"   # 2^10-row tiles of the full basis
     assert pkg.XXZChain(50, nup=3).device_path == "generic"     # 2^38 prefix tiles would not fit a table
 
 

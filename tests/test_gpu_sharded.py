@@ -9,9 +9,15 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("mode", ["range", "class"])
 @pytest.mark.parametrize("L,nup,P,ls", [(16, 8, 2, 8), (16, 8, 3, 8), (18, 9, 8, 9), (20, 10, 4, 12), (17, 6, 5, 8), (14, 7, 8, 13),
-                                        (20, 10, 8, 8), (22, 11, 4, 10)])
+                                        (20, 10, 8, 8), (22, 11, 4, 10),
+                                        # negative ls: tile length classes forced (SD_LEN_CLASSES=2), so the interior and the
+                                        # boundary part are each several launches with 64/128/256-thread workgroups
+                                        (20, 10, 4, -12), (22, 9, 3, -11), (21, 10, 8, -12)])
 def test_virtual_shards_bit_identical(pkg, L, nup, P, ls, mode, monkeypatch):
     import torch
+    if ls < 0:
+        monkeypatch.setenv("SD_LEN_CLASSES", "2")
+        ls = -ls
     monkeypatch.setenv("SD_SUFFIX_BITS", str(ls))
     full = pkg.XXZChain(L, nup=nup)
     rng = np.random.default_rng(L * P)
