@@ -69,6 +69,10 @@ void sd_ctx_destroy(sd_ctx *ctx);
 /* Use an externally owned hipStream_t (e.g. torch's current stream) for all
  * launches of this context; NULL restores the context's own stream. */
 int sd_ctx_set_stream(sd_ctx *ctx, void *hip_stream);
+/* Chebyshev moments (sd_kpm_moments, sd_kpm_sqw): on != 0 (default) computes two moments per apply from
+ * mu_2n = 2<v_n|v_n> - mu_0, mu_2n+1 = 2Re<v_n|v_n+1> - mu_1 (v_n = T_n(H~)phi); on == 0 runs the reference's loop
+ * (src/KPM_Sqw.jl:103-124), one moment <phi|v_k> per apply.  Same moments up to rounding. */
+int sd_ctx_set_kpm_doubling(sd_ctx *ctx, int on);
 int sd_ctx_synchronize(sd_ctx *ctx);
 /* last error text of this context ("" if none); valid until the next call */
 const char *sd_last_error(const sd_ctx *ctx);

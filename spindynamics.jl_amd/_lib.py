@@ -56,6 +56,7 @@ PROTOTYPES = {
     "sd_ctx_create": (_i, [_i, C.POINTER(_vp)]),
     "sd_ctx_destroy": (None, [_vp]),
     "sd_ctx_set_stream": (_i, [_vp, _vp]),
+    "sd_ctx_set_kpm_doubling": (_i, [_vp, _i]),
     "sd_ctx_synchronize": (_i, [_vp]),
     "sd_last_error": (C.c_char_p, [_vp]),
     "sd_status_string": (C.c_char_p, [_i]),
@@ -167,6 +168,10 @@ class Context:
 
     def set_stream(self, stream_ptr):
         check(lib().sd_ctx_set_stream(self.h, _vp(stream_ptr)), self.h)
+
+    def set_kpm_doubling(self, on):
+        """True (default): two Chebyshev moments per apply; False: the reference's one-moment-per-apply loop."""
+        check(lib().sd_ctx_set_kpm_doubling(self.h, 1 if on else 0), self.h)
 
     def synchronize(self):
         check(lib().sd_ctx_synchronize(self.h), self.h)

@@ -119,6 +119,12 @@ int sd_ctx_set_stream(sd_ctx *ctx, void *hip_stream) {
   return SD_OK;
 }
 
+int sd_ctx_set_kpm_doubling(sd_ctx *ctx, int on) {
+  if (!ctx) return SD_EARG;
+  ctx->kpm_doubling = on ? 1 : 0;
+  return SD_OK;
+}
+
 int sd_ctx_synchronize(sd_ctx *ctx) {
   if (!ctx) return SD_EARG;
   SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -286,11 +292,12 @@ int sd_kpm_step_sharded_dev(sd_ctx *ctx, const sd_model *m, void *v_next, const 
                             const void *v_prev, const void *phi, int64_t n_local, double a, double b, int first,
                             double *sums_out) {
   // one KPM recursion step on this shard (src/KPM_Sqw.jl:106-117): first != 0: v_next = H~ v_curr; else
-  // v_next = 2 H~ v_curr - v_prev.  sums_out = local { Re<phi|v_next>, |v_next|^2 } (all-reduce them over the ranks).
+  // v_next = 2 H~ v_curr - v_prev.  sums_out = local { Re<phi|v_next>, |v_next|^2 } (all-reduce them over the ranks);
+  // phi == NULL: Re<v_curr|v_next> instead (moment doubling, no extra vector read).
   int rc = check_apply_args(ctx, m, SD_C128, v_next, v_curr, n_local);
   if (rc) return rc;
   if (n_local != m->n_local) return sd_set_err(ctx, SD_EDIM, "vector length does not match the local basis dimension");
-  if (!phi || !sums_out || (!first && !v_prev)) return sd_set_err(ctx, SD_EARG, "null argument");
+  if (!sums_out || (!first && !v_prev)) return sd_set_err(ctx, SD_EARG, "null argument");   // phi may be null: <v_curr|v_next>
   if (m->n_halo > 0 && !halo) return sd_set_err(ctx, SD_EARG, "this shard needs a halo buffer");
   sd_epi_args ea; ea.a = a; ea.b = b; ea.prev = v_prev; ea.phi = phi; ea.halo = halo;
   rc = sd_launch_apply(ctx, m, SD_C128, v_next, v_curr, first ? SD_EPI_RESCALE_DOT : SD_EPI_KPM, ea, 0);

@@ -92,14 +92,14 @@ __device__ __forceinline__ void epilogue<1>(int epi, const sd_epi_args &ea, int6
     case SD_EPI_RESCALE_DOT: {
       double o = (acc - ea.b * own) / ea.a;
       out[row] = o;
-      double ph = ((const double *)ea.phi)[row];
+      double ph = ea.phi ? ((const double *)ea.phi)[row] : own;   // phi == null: <v_curr|v_next> (moment doubling)
       sums.s0 += ph * o;
       sums.s1 += o * o;
     } break;
     case SD_EPI_KPM: {
       double o = 2.0 * ((acc - ea.b * own) / ea.a) - ((const double *)ea.prev)[row];
       out[row] = o;
-      double ph = ((const double *)ea.phi)[row];
+      double ph = ea.phi ? ((const double *)ea.phi)[row] : own;   // phi == null: <v_curr|v_next> (moment doubling)
       sums.s0 += ph * o;
       sums.s1 += o * o;
     } break;
@@ -132,7 +132,7 @@ __device__ __forceinline__ void epilogue<2>(int epi, const sd_epi_args &ea, int6
     case SD_EPI_RESCALE_DOT: {
       double2 o = make_double2((acc.x - ea.b * own.x) / ea.a, (acc.y - ea.b * own.y) / ea.a);
       o2[row] = o;
-      double2 ph = ((const double2 *)ea.phi)[row];
+      double2 ph = ea.phi ? ((const double2 *)ea.phi)[row] : own;   // phi == null: <v_curr|v_next> (moment doubling)
       sums.s0 += ph.x * o.x + ph.y * o.y;     // Re <phi|o>
       sums.s1 += o.x * o.x + o.y * o.y;
     } break;
@@ -141,7 +141,7 @@ __device__ __forceinline__ void epilogue<2>(int epi, const sd_epi_args &ea, int6
       double2 o = make_double2(2.0 * ((acc.x - ea.b * own.x) / ea.a) - pv.x,
                                2.0 * ((acc.y - ea.b * own.y) / ea.a) - pv.y);
       o2[row] = o;
-      double2 ph = ((const double2 *)ea.phi)[row];
+      double2 ph = ea.phi ? ((const double2 *)ea.phi)[row] : own;
       sums.s0 += ph.x * o.x + ph.y * o.y;
       sums.s1 += o.x * o.x + o.y * o.y;
     } break;

@@ -625,6 +625,35 @@ __global__ __launch_bounds__(1024) void k_reduce_pairs(const double *__restrict_
   if (threadIdx.x == 0) { scalars[0] = a; scalars[1] = b; }
 }
 
+// first stage for long lists (one partial pair per tile: 10^6 pairs at L=32, too long for one workgroup): block j sums
+// the pairs [j*chunk, (j+1)*chunk) into stage[j]; still a fixed order for a given n
+constexpr int SD_RED_STAGE_BLOCKS = 512;
+__global__ __launch_bounds__(256) void k_reduce_pairs_stage(const double *__restrict__ partials, int64_t n, int64_t chunk,
+                                                            double *__restrict__ stage) {
+  __shared__ double red[32];
+  const int64_t lo = (int64_t)blockIdx.x * chunk, hi = lo + chunk < n ? lo + chunk : n;
+  const double2 *__restrict__ p2 = reinterpret_cast<const double2 *>(partials);
+  double a = 0.0, b = 0.0;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) { const double2 v = p2[i]; a += v.x; b += v.y; }
+  block_reduce2(a, b, red);
+  if (threadIdx.x == 0) { stage[2 * blockIdx.x] = a; stage[2 * blockIdx.x + 1] = b; }
+}
+
+// partials[0 .. 2n) -> ctx->d_scalars[0..1]; the caller reserved 2n + 2*SD_RED_STAGE_BLOCKS doubles of ctx->d_partials
+int reduce_pairs(sd_ctx *ctx, int64_t n) {
+  const double *src = ctx->d_partials;
+  if (n > 16384) {
+    double *stage = ctx->d_partials + 2 * n;
+    const int64_t chunk = (n + SD_RED_STAGE_BLOCKS - 1) / SD_RED_STAGE_BLOCKS;
+    hipLaunchKernelGGL(k_reduce_pairs_stage, dim3(SD_RED_STAGE_BLOCKS), dim3(256), 0, ctx->stream, src, n, chunk, stage);
+    SD_HIP(ctx, hipGetLastError());
+    src = stage; n = SD_RED_STAGE_BLOCKS;
+  }
+  hipLaunchKernelGGL(k_reduce_pairs, dim3(1), dim3(1024), 0, ctx->stream, src, n, ctx->d_scalars);
+  SD_HIP(ctx, hipGetLastError());
+  return SD_OK;
+}
+
 template <int NC, int R, int BLOCK, bool FMA>
 int launch_tiled_cfg(sd_ctx *ctx, const sd_dev_model &dm, int nt, size_t shmem, double *out, const double *psi, int epi,
                      const sd_epi_args &ea, int max_len) {
@@ -673,7 +702,7 @@ int sd_launch_apply(sd_ctx *ctx, const sd_model *m, int dtype, void *out, const 
     const int ng = part == 0 ? dm.n_groups : 0;
     if (part == 1) nt = dm.n_interior;
     else if (part == 2) nt = dm.n_singles - dm.n_interior;
-    if (sums) { int rc = sd_ensure_partials(ctx, 2 * (size_t)(nt + ng)); if (rc) return rc; }
+    if (sums) { int rc = sd_ensure_partials(ctx, 2 * (size_t)(nt + ng) + 2 * SD_RED_STAGE_BLOCKS); if (rc) return rc; }
     const int max_len = m->max_tile_len;
     const size_t esz = dtype == SD_C128 ? 16 : 8;
     int rc = SD_OK;
@@ -715,12 +744,12 @@ int sd_launch_apply(sd_ctx *ctx, const sd_model *m, int dtype, void *out, const 
       if (rc) return rc;
     }
     if (sums) {
-      hipLaunchKernelGGL(k_reduce_pairs, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_partials, (int64_t)(nt + ng), ctx->d_scalars);
-      SD_HIP(ctx, hipGetLastError());
+      int rc2 = reduce_pairs(ctx, (int64_t)(nt + ng));
+      if (rc2) return rc2;
     }
   } else if (m->full_ls > 0) {
     const int64_t nb = dm.N >> m->full_ls;
-    if (sums) { int rc = sd_ensure_partials(ctx, 2 * (size_t)nb); if (rc) return rc; }
+    if (sums) { int rc = sd_ensure_partials(ctx, 2 * (size_t)nb + 2 * SD_RED_STAGE_BLOCKS); if (rc) return rc; }
     const size_t esz = dtype == SD_C128 ? 16 : 8;
     const size_t shmem = (((size_t)1 << m->full_ls) + 1) * esz + 32 * sizeof(double) + 16;
     void (*kf)(sd_dev_model, double *, const double *, int, sd_epi_args, double *) =
@@ -730,13 +759,13 @@ int sd_launch_apply(sd_ctx *ctx, const sd_model *m, int dtype, void *out, const 
                        ctx->d_partials);
     SD_HIP(ctx, hipGetLastError());
     if (sums) {
-      hipLaunchKernelGGL(k_reduce_pairs, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_partials, nb, ctx->d_scalars);
-      SD_HIP(ctx, hipGetLastError());
+      int rc2 = reduce_pairs(ctx, (int64_t)nb);
+      if (rc2) return rc2;
     }
   } else {
     int64_t nb = (dm.N + 255) / 256;
     if (nb > 8192) nb = 8192;
-    if (sums) { int rc = sd_ensure_partials(ctx, 2 * (size_t)nb); if (rc) return rc; }
+    if (sums) { int rc = sd_ensure_partials(ctx, 2 * (size_t)nb + 2 * SD_RED_STAGE_BLOCKS); if (rc) return rc; }
     if (dtype == SD_C128)
       hipLaunchKernelGGL(k_apply_generic<2>, dim3((unsigned)nb), dim3(256), 0, ctx->stream, dm, (double *)out,
                          (const double *)psi, epi, ea, ctx->d_partials);
@@ -745,8 +774,8 @@ int sd_launch_apply(sd_ctx *ctx, const sd_model *m, int dtype, void *out, const 
                          (const double *)psi, epi, ea, ctx->d_partials);
     SD_HIP(ctx, hipGetLastError());
     if (sums) {
-      hipLaunchKernelGGL(k_reduce_pairs, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_partials, nb, ctx->d_scalars);
-      SD_HIP(ctx, hipGetLastError());
+      int rc2 = reduce_pairs(ctx, (int64_t)nb);
+      if (rc2) return rc2;
     }
   }
   return SD_OK;

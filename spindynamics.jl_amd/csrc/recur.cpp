@@ -113,21 +113,49 @@ int moments_dev(sd_ctx *ctx, const sd_model *m, const double *phi, int M, double
   if (M < 2) return sd_set_err(ctx, SD_EARG, "kpm_m must be >= 2");
   DBuf b0, b1, b2;
   RC(b0.alloc(ctx, 2 * N)); RC(b1.alloc(ctx, 2 * N)); RC(b2.alloc(ctx, 2 * N));
-  double *v_prev = b0.p, *v_curr = b1.p, *v_next = b2.p;
-  RC(d2d(ctx, v_prev, phi, 2 * N));
   double s[2];
-  RC(sd_k_dot(ctx, 2, phi, v_prev, N, 4)); RC(sd_read_scalars(ctx, 4, 2, s)); mu[0] = s[0];      // :103
-  sd_epi_args ea; ea.a = a; ea.b = b; ea.phi = phi;
-  RC(sd_launch_apply(ctx, m, SD_C128, v_curr, v_prev, SD_EPI_RESCALE_DOT, ea));                   // :106-107
-  RC(sd_read_scalars(ctx, 0, 2, s)); mu[1] = s[0];
-  for (int k = 2; k <= M - 1; ++k) {
-    ea.prev = v_prev;
-    RC(sd_launch_apply(ctx, m, SD_C128, v_next, v_curr, SD_EPI_KPM, ea));                         // :111-117 fused
+  for (int doubling = ctx->kpm_doubling ? 1 : 0; doubling >= 0; --doubling) {
+    double *v_prev = b0.p, *v_curr = b1.p, *v_next = b2.p;
+    RC(d2d(ctx, v_prev, phi, 2 * N));
+    RC(sd_k_dot(ctx, 2, phi, v_prev, N, 4)); RC(sd_read_scalars(ctx, 4, 2, s)); mu[0] = s[0];      // :103
+    sd_epi_args ea; ea.a = a; ea.b = b;
+    if (!doubling) {
+      // the reference's recursion: one moment <phi|T_k phi> per apply
+      ea.phi = phi;
+      RC(sd_launch_apply(ctx, m, SD_C128, v_curr, v_prev, SD_EPI_RESCALE_DOT, ea));                 // :106-107
+      RC(sd_read_scalars(ctx, 0, 2, s)); mu[1] = s[0];
+      for (int k = 2; k <= M - 1; ++k) {
+        ea.prev = v_prev;
+        RC(sd_launch_apply(ctx, m, SD_C128, v_next, v_curr, SD_EPI_KPM, ea));                       // :111-117 fused
+        RC(sd_read_scalars(ctx, 0, 2, s));
+        mu[k] = s[0];
+        const double nv = std::sqrt(s[1]);
+        if (nv > 1e3) RC(sd_k_scale_div(ctx, v_next, v_next, 2 * N, nv));                           // :118-121
+        double *t = v_prev; v_prev = v_curr; v_curr = v_next; v_next = t;                           // :124
+      }
+      return SD_OK;
+    }
+    // Two moments per apply from the same vectors v_n = T_n(H~) phi (T_m T_n = (T_{m+n} + T_{|m-n|})/2, H~ Hermitian):
+    //   mu_{2n}   = 2 <v_n|v_n>       - mu_0,      mu_{2n+1} = 2 Re<v_n|v_{n+1}> - mu_1.
+    // Same moments as the reference's loop up to rounding (<= 1e-13 here), in half the applies and without re-reading phi.
+    // If the reference's overflow guard (:118-121, |v| > 1e3: the bounds do not contain the spectrum) would fire, the
+    // identity no longer mirrors what the reference computes, so the reference recursion is run instead.
+    ea.phi = nullptr;                                           // epilogue: s0 = Re<v_curr|v_next>, s1 = |v_next|^2
+    RC(sd_launch_apply(ctx, m, SD_C128, v_curr, v_prev, SD_EPI_RESCALE_DOT, ea));
     RC(sd_read_scalars(ctx, 0, 2, s));
-    mu[k] = s[0];
-    const double nv = std::sqrt(s[1]);
-    if (nv > 1e3) RC(sd_k_scale_div(ctx, v_next, v_next, 2 * N, nv));                             // :118-121
-    double *t = v_prev; v_prev = v_curr; v_curr = v_next; v_next = t;                             // :124
+    mu[1] = s[0];
+    if (M > 2) mu[2] = 2.0 * s[1] - mu[0];
+    bool guard = false;
+    for (int n = 1; 2 * n + 1 <= M - 1 && !guard; ++n) {
+      ea.prev = v_prev;
+      RC(sd_launch_apply(ctx, m, SD_C128, v_next, v_curr, SD_EPI_KPM, ea));                         // v_{n+1}
+      RC(sd_read_scalars(ctx, 0, 2, s));
+      mu[2 * n + 1] = 2.0 * s[0] - mu[1];
+      if (2 * n + 2 <= M - 1) mu[2 * n + 2] = 2.0 * s[1] - mu[0];
+      if (std::sqrt(s[1]) > 1e3) guard = true;
+      double *t = v_prev; v_prev = v_curr; v_curr = v_next; v_next = t;
+    }
+    if (!guard) return SD_OK;
   }
   return SD_OK;
 }

@@ -51,6 +51,7 @@ struct sd_ctx {
   double *d_scalars = nullptr;  // 16 doubles, device
   double *h_scalars = nullptr;  // 16 doubles, pinned host
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  int kpm_doubling = 1;     // sd_ctx_set_kpm_doubling: two Chebyshev moments per apply (default) or the reference's one
 };
 
 // Device-side view of a model, passed by value to kernels.

@@ -224,8 +224,10 @@ class ShardedOperator:
             check(lib().sd_szq_dev(m.ctx.h, m.h, code, psi0.data_ptr(), self.n_local, float(q), phi.data_ptr()), m.ctx.h)
         return phi
 
-    def kpm_moments(self, phi, M, a, b, group=None):
-        """compute_chebyshev_moments (src/KPM_Sqw.jl:95-128) for a normalised sharded phi; returns mu[0..M)."""
+    def kpm_moments(self, phi, M, a, b, group=None, doubling=True):
+        """compute_chebyshev_moments (src/KPM_Sqw.jl:95-128) for a normalised sharded phi; returns mu[0..M).
+        doubling (default): two moments per apply, mu_2n = 2<v_n|v_n> - mu_0, mu_2n+1 = 2Re<v_n|v_n+1> - mu_1;
+        doubling=False: the reference's loop, one moment <phi|v_k> per apply."""
         import ctypes as C
         import numpy as np
         import torch
@@ -236,7 +238,8 @@ class ShardedOperator:
         v_prev, v_curr, v_next = phi.clone(), torch.empty_like(phi), torch.empty_like(phi)
         mu[0] = self.dot(phi, v_prev, group).real
         sums = (C.c_double * 2)()
-        for k in range(1, M):
+        nsteps = (M // 2) if doubling else (M - 1)      # applies: v_1 .. v_nsteps
+        for k in range(1, nsteps + 1):
             src = v_prev if k == 1 else v_curr
             dst = v_curr if k == 1 else v_next
             halo = self.exchange(src, group)
@@ -245,15 +248,26 @@ class ShardedOperator:
                 m.ctx.set_stream(torch.cuda.current_stream(phi.device).cuda_stream)
                 check(lib().sd_kpm_step_sharded_dev(m.ctx.h, m.h, dst.data_ptr(), src.data_ptr(),
                                                     halo.data_ptr() if self.n_halo else None,
-                                                    v_prev.data_ptr(), phi.data_ptr(), self.n_local, float(a), float(b),
-                                                    1 if k == 1 else 0, sums), m.ctx.h)
+                                                    v_prev.data_ptr(), None if doubling else phi.data_ptr(), self.n_local,
+                                                    float(a), float(b), 1 if k == 1 else 0, sums), m.ctx.h)
                 loc = [sums[0], sums[1]]
             tot = self._allreduce(loc, phi.device, group)
-            mu[k] = tot[0]
+            if doubling:                                # tot = [Re<v_{k-1}|v_k>, |v_k|^2]
+                if k == 1:
+                    mu[1] = tot[0]
+                elif 2 * k - 1 <= M - 1:
+                    mu[2 * k - 1] = 2.0 * tot[0] - mu[1]
+                if 2 * k <= M - 1:
+                    mu[2 * k] = 2.0 * tot[1] - mu[0]
+                if float(np.sqrt(tot[1])) > 1e3:        # bounds do not contain the spectrum: mirror the reference's loop
+                    return self.kpm_moments(phi, M, a, b, group, doubling=False)
+            else:
+                mu[k] = tot[0]
             if k >= 2:
-                nv = float(np.sqrt(tot[1]))
-                if nv > 1e3:                       # src/KPM_Sqw.jl:117-121
-                    v_next /= nv
+                if not doubling:
+                    nv = float(np.sqrt(tot[1]))
+                    if nv > 1e3:                       # src/KPM_Sqw.jl:117-121
+                        v_next /= nv
                 v_prev, v_curr, v_next = v_curr, v_next, v_prev
         return mu
 

@@ -171,6 +171,47 @@ def test_kpm_and_sqw_vs_oracle(pkg, O, L, nup, Jxy, Jz, bc):
     assert np.abs(Sg - O.lanczos_sqw(r, gs, q[1:2], omega, lanc_m=12, eta=0.1, broaden="gauss")).max() <= 1e-8
 
 
+@pytest.mark.parametrize("M", [2, 3, 4, 7, 64, 201])
+def test_kpm_moment_doubling_equals_reference_loop(pkg, O, M):
+    """Default: two moments per apply (mu_2n = 2<v_n|v_n> - mu_0, mu_2n+1 = 2Re<v_n|v_n+1> - mu_1).  It must give the
+    moments of the reference's one-per-apply loop (src/KPM_Sqw.jl:103-124, = the oracle) to rounding: tolerance 1e-13
+    absolute on moments of a normalised phi, for even and odd M."""
+    L, nup = 14, 7
+    m = pkg.XXZChain(L, Jz=0.8, nup=nup)
+    r = O.XXZChain(L, Jz=0.8, nup=nup)
+    rng = np.random.default_rng(M)
+    phi = rng.standard_normal(m.N) + 1j * rng.standard_normal(m.N)
+    phi /= np.linalg.norm(phi)
+    a, b = O.rescaling_from_bounds(-L / 2, L / 2)
+    want = O.compute_chebyshev_moments(r, phi, M, a, b)
+    try:
+        m.ctx.set_kpm_doubling(True)
+        mu_d = pkg.compute_chebyshev_moments(pkg.apply_H, phi, M, a, b, m)
+        m.ctx.set_kpm_doubling(False)
+        mu_r = pkg.compute_chebyshev_moments(pkg.apply_H, phi, M, a, b, m)
+    finally:
+        m.ctx.set_kpm_doubling(True)
+    assert mu_d.shape == mu_r.shape == (M,)
+    assert np.abs(mu_r - want).max() <= 1e-13
+    assert np.abs(mu_d - want).max() <= 1e-13
+
+
+def test_kpm_doubling_falls_back_when_the_reference_guard_fires(pkg, O):
+    """Bounds that do not contain the spectrum: |v_k| grows past 1e3 and the reference renormalises v_next
+    (src/KPM_Sqw.jl:118-121).  The doubling identity does not describe that sequence, so the library reruns the
+    reference loop; the moments then follow the oracle's (they grow like cosh, so the comparison is relative)."""
+    L, nup = 12, 6
+    m = pkg.XXZChain(L, nup=nup)
+    r = O.XXZChain(L, nup=nup)
+    phi = np.random.default_rng(1).standard_normal(m.N) + 0j
+    phi /= np.linalg.norm(phi)
+    a, b = 0.6, 0.0                                   # spectrum is ~[-5.4, 2.8] / 0.6: far outside [-1, 1]
+    mu = pkg.compute_chebyshev_moments(pkg.apply_H, phi, 24, a, b, m)
+    want = O.compute_chebyshev_moments(r, phi, 24, a, b)
+    assert np.abs(want).max() > 100.0                 # far outside a Chebyshev moment's range [-1, 1]: the guard fired
+    assert np.abs(mu - want).max() <= 1e-9 * np.abs(want).max()
+
+
 def test_fused_epilogues_vs_unfused_device_ops(pkg, O):
     """apply_rescaled / Chebyshev step on torch device tensors equal the oracle's un-fused passes bit for bit."""
     import torch

@@ -119,3 +119,11 @@ def test_sharded_kpm_driver_matches_oracle(pkg, O, monkeypatch):
     S = op.kpm_sqw(torch.from_numpy(psi0).cuda(), q, omega, a, b, kpm_m=96)
     S2 = O.kpm_sqw(r, psi0, q, omega, a, b, kpm_m=96)
     assert np.abs(S - S2).max() <= 1e-8 * max(1.0, np.abs(S2).max())
+    # the moment loop itself, doubling (default) and the reference's one-moment-per-apply form, odd and even M
+    phi = np.asarray(O.Sz_q_vector(r, psi0, float(q[1])))
+    phi /= np.linalg.norm(phi)
+    tphi = torch.from_numpy(phi).cuda()
+    for M in (2, 3, 8, 33):
+        want = O.compute_chebyshev_moments(r, phi, M, a, b)
+        assert np.abs(op.kpm_moments(tphi, M, a, b) - want).max() <= 1e-13
+        assert np.abs(op.kpm_moments(tphi, M, a, b, doubling=False) - want).max() <= 1e-13
