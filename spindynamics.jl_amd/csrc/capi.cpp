@@ -48,6 +48,7 @@ int check_apply_args(sd_ctx *ctx, const sd_model *m, int dtype, const void *out,
   if (dtype != SD_F64 && dtype != SD_C128) return sd_set_err(ctx, SD_EARG, "dtype must be SD_F64 or SD_C128");
   if (!out || !psi) return sd_set_err(ctx, SD_EARG, "null vector");
   if (out == psi) return sd_set_err(ctx, SD_EARG, "out must not alias psi");
+  SD_HIP(ctx, hipSetDevice(ctx->device));   // the caller's thread may have another device current (several contexts per process)
   return SD_OK;
 }
 }  // namespace
@@ -116,6 +117,7 @@ void sd_ctx_destroy(sd_ctx *c) {
 int sd_ctx_set_stream(sd_ctx *ctx, void *hip_stream) {
   if (!ctx) return SD_EARG;
   ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+  SD_HIP(ctx, hipSetDevice(ctx->device));
   return SD_OK;
 }
 

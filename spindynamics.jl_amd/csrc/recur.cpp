@@ -56,6 +56,7 @@ int check_unsharded(sd_ctx *ctx, const sd_model *m) {
   if (!ctx) return SD_EARG;
   if (!m || !m->dev_ready) return sd_set_err(ctx, SD_EARG, "model has no device tables");
   if (m->nranks != 1) return sd_set_err(ctx, SD_EARG, "recursion-level entry points run on an unsharded model");
+  SD_HIP(ctx, hipSetDevice(ctx->device));
   return SD_OK;
 }
 
