@@ -113,7 +113,9 @@ def main():
         return bool(ok.item() == 1.0)
 
     check = "uniform state exact eigenvector on all ranks"
-    if not selfcheck():
+    if os.environ.get("SD_DEBUG_SKIP", "0") not in ("", "0"):
+        check = "SKIPPED: SD_DEBUG_SKIP timing ablation (results are wrong by construction)"
+    elif not selfcheck():
         # fall back to the simplest distributed path before giving up: index ranges, no overlap
         if world > 1 and op.mode == "class":
             model = pkg.XXZChain(L, nup=nup)

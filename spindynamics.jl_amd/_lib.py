@@ -9,7 +9,7 @@ import os
 import sys
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libspindyn.so")
+LIB_PATH = os.environ.get("SD_LIB_PATH") or os.path.join(_PKG, "libspindyn.so")   # SD_LIB_PATH: A/B builds of the same ABI
 
 SD_OK, SD_EARG, SD_EDIM, SD_EZERO, SD_ENOMEM, SD_EHIP, SD_ENODEV, SD_EINTERNAL = range(8)
 SD_F64, SD_C128 = 1, 2

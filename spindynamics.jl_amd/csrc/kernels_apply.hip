@@ -110,7 +110,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_apply_tiled(sd_dev_model dm, doubl
     bool fl = false;
     const int b = lane + 1;
     if (b <= p - 1) {
-      fl = (((P >> (b - 1)) ^ (P >> b)) & 1u) && !(dm.dbg & 1);
+      fl = (((P >> (b - 1)) ^ (P >> b)) & 1u) && !(DIAG && (dm.dbg & 1));
       if (fl) { my_base = dm.addr[P ^ (3u << (b - 1))]; my_J = dm.hop_J[b - 1]; }
     } else if (b == p) {
       // bit p of P up:   our rows with first suffix site down (i >= nU) <-> partner rows i - nU
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_apply_tiled(sd_dev_model dm, doubl
       const uint32_t bitp = (P >> (p - 1)) & 1u;
       const uint32_t Q = P ^ (1u << (p - 1));
       const int t2q = dm.nup - __popc(Q);
-      if (t2q >= 0 && t2q <= LS && !(dm.dbg & 2)) {
+      if (t2q >= 0 && t2q <= LS && !(DIAG && (dm.dbg & 2))) {
         const int nUq = (int)binom_g(dm, LS - 1, t2q - 1);
         int64_t shift;
         if (bitp) { my_lo = nU; my_n = len - nU; shift = 0; }
@@ -172,6 +172,10 @@ __global__ __launch_bounds__(BLOCK, 4) void k_apply_tiled(sd_dev_model dm, doubl
   }
 
   SD_STAMP(2);
+  // The only barrier: own rows and binomials are in LDS.  Placed BEFORE the far-bond streams (all waves are at the same
+  // point here, their own rows have just arrived), so that afterwards every wave runs its stream and suffix phases on
+  // its own clock and one wave's LDS/VALU phase overlaps its neighbours' memory phase.
+  __syncthreads();
   // ---- 3. far bonds: ping-pong pipeline, accumulation in bond order ----
   while (have_a) {
     bool have_b = false;
@@ -185,11 +189,10 @@ __global__ __launch_bounds__(BLOCK, 4) void k_apply_tiled(sd_dev_model dm, doubl
     for (int r = 0; r < R; ++r) acc[r] = accum<FMA>(acc[r], fbb.J, vb[r]);
   }
   SD_STAMP(3);
-  __syncthreads();
   SD_STAMP(4);
 
   // ---- 4. bonds inside the suffix: LDS reads at idx +- C(LS-a-1, u); branch-free so the R rows' reads overlap ----
-  if (nn > 0 && !(dm.dbg & 4)) {
+  if (nn > 0 && !(DIAG && (dm.dbg & 4))) {
     uint32_t dw[R];   // bit a-1 set <=> suffix bond a is flippable
 #pragma unroll
     for (int r = 0; r < R; ++r) dw[r] = sig[r] ^ (sig[r] >> 1);
@@ -659,8 +662,9 @@ int launch_tiled_cfg(sd_ctx *ctx, const sd_dev_model &dm, int nt, size_t shmem, 
                      const sd_epi_args &ea, int max_len) {
   // the stamped (DIAG) instantiation exists for one configuration only and is reached through sd_debug_phase_profile
   void (*kern)(sd_dev_model, double *, const double *, int, sd_epi_args, double *, int) = k_apply_tiled<NC, R, BLOCK, FMA>;
-  if constexpr (NC == 2 && BLOCK == 256 && FMA)
-    if (dm.stamps) kern = k_apply_tiled<NC, R, BLOCK, FMA, true>;
+  // ... and for the SD_DEBUG_SKIP timing ablations: the production instantiations carry no run-time debug branches
+  if constexpr (NC == 2 && FMA && (BLOCK == 256 || BLOCK == 128 || BLOCK == 64))
+    if (dm.stamps || dm.dbg) kern = k_apply_tiled<NC, R, BLOCK, FMA, true>;
   static size_t attr_set = 0;
   if (shmem > 48 * 1024 && shmem > attr_set) {
     SD_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
