@@ -147,6 +147,24 @@ __global__ __launch_bounds__(BS) void k_caxpy(double2 *__restrict__ w, const dou
   }
 }
 
+// y (+)= sum_k (cr[k] + i ci[k]) * X_k, columns given by pointer, accumulated in column order with exactly the arithmetic
+// of one k_caxpy<1> pass per column (psi_t .+= y[k] * V[k], src/TimeEvolution/Krylov.jl:186-188): same bits, one read of
+// every column and one write of y instead of a read-modify-write of y per column.
+constexpr int SD_CCOMB_MAXC = 16;
+struct CCombArgs { const double2 *x[SD_CCOMB_MAXC]; double cr[SD_CCOMB_MAXC], ci[SD_CCOMB_MAXC]; };
+__global__ __launch_bounds__(BS) void k_ccombine(double2 *__restrict__ y, int64_t N, int nc, CCombArgs a, int init) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += stride) {
+    double2 acc = init ? make_double2(0.0, 0.0) : y[i];
+    for (int k = 0; k < nc; ++k) {
+      const double2 x = a.x[k][i];
+      const double tr = a.cr[k] * x.x - a.ci[k] * x.y, ti = a.cr[k] * x.y + a.ci[k] * x.x;
+      acc.x += tr; acc.y += ti;
+    }
+    y[i] = acc;
+  }
+}
+
 __global__ __launch_bounds__(BS) void k_cheb_init(double2 *__restrict__ y, const double2 *__restrict__ x0,
                                                   const double2 *__restrict__ x1, int64_t N, double c0r, double c0i,
                                                   double c1r, double c1i, int have1) {
@@ -280,6 +298,20 @@ int sd_k_csub(sd_ctx *ctx, double *w, const double *v, int64_t N, double ar, dou
 int sd_k_cacc(sd_ctx *ctx, double *y, const double *x, int64_t N, double ar, double ai) {
   hipLaunchKernelGGL(k_caxpy<1>, dim3(grid_for(N)), dim3(BS), 0, ctx->stream, (double2 *)y, (const double2 *)x, N, ar, ai);
   SD_HIP(ctx, hipGetLastError());
+  return SD_OK;
+}
+int sd_k_ccombine(sd_ctx *ctx, double *y, const double *const *cols, int64_t N, int ncols, const double *cr, const double *ci) {
+  if (ncols == 0) { SD_HIP(ctx, hipMemsetAsync(y, 0, sizeof(double) * 2 * N, ctx->stream)); return SD_OK; }
+  for (int k0 = 0; k0 < ncols; k0 += SD_CCOMB_MAXC) {
+    CCombArgs a;
+    const int nc = std::min(SD_CCOMB_MAXC, ncols - k0);
+    for (int k = 0; k < SD_CCOMB_MAXC; ++k) {
+      a.x[k] = k < nc ? (const double2 *)cols[k0 + k] : nullptr;
+      a.cr[k] = k < nc ? cr[k0 + k] : 0.0; a.ci[k] = k < nc ? ci[k0 + k] : 0.0;
+    }
+    hipLaunchKernelGGL(k_ccombine, dim3(grid_for(N)), dim3(BS), 0, ctx->stream, (double2 *)y, N, nc, a, k0 == 0 ? 1 : 0);
+    SD_HIP(ctx, hipGetLastError());
+  }
   return SD_OK;
 }
 int sd_k_cheb_init(sd_ctx *ctx, double *y, const double *x0, const double *x1, int64_t N, double c0r, double c0i,

@@ -497,8 +497,11 @@ extern "C" int sd_krylov_evolve(sd_ctx *ctx, const sd_model *m, int dtype, const
       yr[k] += qk * cr * q0; yi[k] += qk * ci * q0;
     }
   }
-  SD_HIP(ctx, hipMemsetAsync(w.p, 0, sizeof(double) * 2 * n, ctx->stream));             // :185
-  for (int k = 0; k < m_eff; ++k) RC(sd_k_cacc(ctx, w.p, V[k].p, n, yr[k], yi[k]));       // :186-188
+  {                                                                                       // :185-188, one fused pass
+    std::vector<const double *> cols(m_eff);
+    for (int k = 0; k < m_eff; ++k) cols[k] = V[k].p;
+    RC(sd_k_ccombine(ctx, w.p, cols.data(), n, m_eff, yr.data(), yi.data()));
+  }
   const double nn = norm_dev(ctx, w.p, 2 * n, &rc); RC(rc);
   RC(sd_k_scale_div(ctx, w.p, w.p, 2 * n, nn));                                           // :190
   RC(d2h(ctx, psit, w.p, 2 * n));

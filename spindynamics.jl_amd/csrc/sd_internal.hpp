@@ -196,6 +196,8 @@ int sd_k_krylov_update_nrm(sd_ctx *ctx, double *w, const double *v, const double
 // w -= (ar + i ai) * v  for complex vectors (src/TimeEvolution/Krylov.jl:156)
 int sd_k_csub(sd_ctx *ctx, double *w, const double *v, int64_t N, double ar, double ai);
 // y += (ar + i ai) * x  complex accumulate (Krylov reconstruction :186-188)
+int sd_k_ccombine(sd_ctx *ctx, double *y, const double *const *cols, int64_t N, int ncols, const double *cr,
+                  const double *ci);   // y = sum_k (cr+i ci)[k] * cols[k], column order, bit-identical to ncols k_cacc passes on y = 0
 int sd_k_cacc(sd_ctx *ctx, double *y, const double *x, int64_t N, double ar, double ai);
 // y = c0*x0 (+ c1*x1) complex  (Chebyshev start, src/TimeEvolution/Chebyshev.jl:96-102)
 int sd_k_cheb_init(sd_ctx *ctx, double *y, const double *x0, const double *x1, int64_t N, double c0r, double c0i,
