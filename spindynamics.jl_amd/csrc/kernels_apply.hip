@@ -191,6 +191,25 @@ __global__ __launch_bounds__(BLOCK, 4) void k_apply_tiled(sd_dev_model dm, doubl
   SD_STAMP(3);
   SD_STAMP(4);
 
+  // ---- first general bond (e.g. the periodic (L,1) bond): its gathers are requested now, into the idle stream registers,
+  // so that their latency hides behind the suffix phase; they are accumulated in their turn, after the suffix bonds ----
+  const uint64_t pmask = ((uint64_t)1 << p) - 1;
+  const bool have_g = nn < dm.n_hop;
+  double gJ = 0.0;
+  if (have_g) {
+    const int bi = dm.hop_i[nn] - 1, bj = dm.hop_j[nn] - 1;
+    gJ = dm.hop_J[nn];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const uint64_t s = (uint64_t)P | ((uint64_t)sig[r] << p);
+      va[r] = V{};
+      if (((s >> bi) ^ (s >> bj)) & 1) {
+        const uint64_t s2 = s ^ ((uint64_t)1 << bi) ^ ((uint64_t)1 << bj);
+        const int64_t idx = dm.addr[(uint32_t)(s2 & pmask)] + dm.suf_rank[(uint32_t)(s2 >> p)];
+        va[r] = (halo && idx >= dm.n_local) ? halo[idx - dm.n_local] : psi[idx];
+      }
+    }
+  }
   // ---- 4. bonds inside the suffix: LDS reads at idx +- C(LS-a-1, u); branch-free so the R rows' reads overlap ----
   if (nn > 0 && !(DIAG && (dm.dbg & 4))) {
     uint32_t dw[R];   // bit a-1 set <=> suffix bond a is flippable
@@ -215,9 +234,14 @@ __global__ __launch_bounds__(BLOCK, 4) void k_apply_tiled(sd_dev_model dm, doubl
     }
   }
   // ---- remaining (general) bonds: rank through the tile tables ----
-  if (nn < dm.n_hop) {
-    const uint64_t pmask = ((uint64_t)1 << p) - 1;
-    for (int h = nn; h < dm.n_hop; ++h) {
+  if (have_g) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const uint64_t s = (uint64_t)P | ((uint64_t)sig[r] << p);
+      const int bi = dm.hop_i[nn] - 1, bj = dm.hop_j[nn] - 1;
+      if (((s >> bi) ^ (s >> bj)) & 1) acc[r] = accum<false>(acc[r], gJ, va[r]);   // rows without the hop keep acc untouched
+    }
+    for (int h = nn + 1; h < dm.n_hop; ++h) {
       const int bi = dm.hop_i[h] - 1, bj = dm.hop_j[h] - 1;
       const double J = dm.hop_J[h];
 #pragma unroll
