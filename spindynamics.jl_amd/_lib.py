@@ -57,6 +57,7 @@ PROTOTYPES = {
     "sd_ctx_destroy": (None, [_vp]),
     "sd_ctx_set_stream": (_i, [_vp, _vp]),
     "sd_ctx_set_kpm_doubling": (_i, [_vp, _i]),
+    "sd_ctx_release_scratch": (_i, [_vp]),
     "sd_ctx_synchronize": (_i, [_vp]),
     "sd_last_error": (C.c_char_p, [_vp]),
     "sd_status_string": (C.c_char_p, [_i]),
@@ -172,6 +173,10 @@ class Context:
     def set_kpm_doubling(self, on):
         """True (default): two Chebyshev moments per apply; False: the reference's one-moment-per-apply loop."""
         check(lib().sd_ctx_set_kpm_doubling(self.h, 1 if on else 0), self.h)
+
+    def release_scratch(self):
+        """Free the staging buffers kept between host-pointer apply calls (re-created on demand)."""
+        check(lib().sd_ctx_release_scratch(self.h), self.h)
 
     def synchronize(self):
         check(lib().sd_ctx_synchronize(self.h), self.h)

@@ -41,6 +41,19 @@ struct TmpDev {
   }
 };
 
+// grow-only device staging buffers of a context: a solver that calls sd_apply in a loop pays hipMalloc/hipFree once
+int stage_buf(sd_ctx *ctx, int which, size_t bytes, void **out) {
+  if (ctx->stage_cap[which] < bytes) {
+    if (ctx->stage[which]) (void)hipFree(ctx->stage[which]);
+    ctx->stage[which] = nullptr; ctx->stage_cap[which] = 0;
+    hipError_t e = hipMalloc(&ctx->stage[which], bytes ? bytes : 1);
+    if (e != hipSuccess) return sd_set_err(ctx, SD_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    ctx->stage_cap[which] = bytes;
+  }
+  *out = ctx->stage[which];
+  return SD_OK;
+}
+
 int check_apply_args(sd_ctx *ctx, const sd_model *m, int dtype, const void *out, const void *psi, int64_t n) {
   if (!ctx) return SD_EARG;
   if (!m) return sd_set_err(ctx, SD_EARG, "null model");
@@ -106,6 +119,7 @@ void sd_ctx_destroy(sd_ctx *c) {
   if (!c) return;
   if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
   if (c->d_partials) (void)hipFree(c->d_partials);
+  for (void *b : c->stage) if (b) (void)hipFree(b);
   if (c->d_scalars) (void)hipFree(c->d_scalars);
   if (c->h_scalars) (void)hipHostFree(c->h_scalars);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -124,6 +138,18 @@ int sd_ctx_set_stream(sd_ctx *ctx, void *hip_stream) {
 int sd_ctx_set_kpm_doubling(sd_ctx *ctx, int on) {
   if (!ctx) return SD_EARG;
   ctx->kpm_doubling = on ? 1 : 0;
+  return SD_OK;
+}
+
+int sd_ctx_release_scratch(sd_ctx *ctx) {
+  if (!ctx) return SD_EARG;
+  SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (int k = 0; k < 2; ++k) {
+    if (ctx->stage[k]) (void)hipFree(ctx->stage[k]);
+    ctx->stage[k] = nullptr; ctx->stage_cap[k] = 0;
+  }
+  if (ctx->d_partials) (void)hipFree(ctx->d_partials);
+  ctx->d_partials = nullptr; ctx->partials_cap = 0;
   return SD_OK;
 }
 
@@ -354,13 +380,13 @@ static int apply_host(sd_ctx *ctx, const sd_model *m, int dtype, void *out, cons
   if (m->nranks != 1) return sd_set_err(ctx, SD_EARG, "host-pointer applies need an unsharded model");
   if (n != m->N) return sd_set_err(ctx, SD_EDIM, "vector length does not match the basis dimension");
   const size_t bytes = (size_t)n * (dtype == SD_C128 ? 16 : 8);
-  TmpDev din(ctx), dout(ctx);
-  if ((rc = din.alloc(bytes)) || (rc = dout.alloc(bytes))) return rc;
-  SD_HIP(ctx, hipMemcpyAsync(din.p, psi, bytes, hipMemcpyHostToDevice, ctx->stream));
+  void *din, *dout;
+  if ((rc = stage_buf(ctx, 0, bytes, &din)) || (rc = stage_buf(ctx, 1, bytes, &dout))) return rc;
+  SD_HIP(ctx, hipMemcpyAsync(din, psi, bytes, hipMemcpyHostToDevice, ctx->stream));
   sd_epi_args ea; ea.a = a; ea.b = b;
-  rc = sd_launch_apply(ctx, m, dtype, dout.p, din.p, epi, ea);
+  rc = sd_launch_apply(ctx, m, dtype, dout, din, epi, ea);
   if (rc) return rc;
-  SD_HIP(ctx, hipMemcpyAsync(out, dout.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  SD_HIP(ctx, hipMemcpyAsync(out, dout, bytes, hipMemcpyDeviceToHost, ctx->stream));
   SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return SD_OK;
 }

@@ -51,6 +51,8 @@ struct sd_ctx {
   double *d_scalars = nullptr;  // 16 doubles, device
   double *h_scalars = nullptr;  // 16 doubles, pinned host
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  void *stage[2] = {nullptr, nullptr};   // device staging of the host-pointer operator calls (sd_apply, ...), kept between calls
+  size_t stage_cap[2] = {0, 0};
   int kpm_doubling = 1;     // sd_ctx_set_kpm_doubling: two Chebyshev moments per apply (default) or the reference's one
 };
 

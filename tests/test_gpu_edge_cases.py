@@ -83,3 +83,19 @@ def test_kpm_sum_rule_medium_size(pkg):
     for iq in range(2):
         w = np.linalg.norm(pkg.Sz_q_vector(m, psi0, float(q[iq]))) ** 2
         assert abs(S[iq].sum() * 0.01 - w) <= 1e-2 * w
+
+
+def test_host_pointer_applies_reuse_and_release_staging(pkg, O):
+    """sd_apply keeps its two device staging vectors in the context between calls (grow-only); sizes going up and down and
+    an explicit release must not change results."""
+    ctx = pkg.XXZChain(4, nup=2).ctx
+    for (L, nup) in [(12, 6), (16, 8), (10, 5), (16, 7)]:
+        m = pkg.XXZChain(L, nup=nup, Jz=0.4)
+        r = O.XXZChain(L, nup=nup, Jz=0.4)
+        psi = np.random.default_rng(L + nup).standard_normal(m.N) + 0j
+        out = np.empty_like(psi)
+        for _ in range(2):
+            pkg.apply_H(out, psi, m)
+            assert np.array_equal(out, O.apply_H(r, psi))
+        if L == 16 and nup == 8:
+            ctx.release_scratch()
