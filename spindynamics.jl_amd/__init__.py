@@ -19,6 +19,6 @@ from .observables import connected_correlations, magnetization_per_site, structu
 from . import initial_states
 from .initial_states import domain_wall_state, neel_state, polarized_state, polarized_state_with_flips
 from .api import dynamical_structure_factor, groundstate, structure_factor, time_evolve
-from .dist import ShardedOperator
+from .dist import ShardedOperator, kpm_sqw_replicas
 
 __all__ = [n for n in dir() if not n.startswith("_")]

@@ -314,3 +314,35 @@ class ShardedOperator:
             code = _lib.SD_C128 if x.is_complex() else _lib.SD_F64
             check(lib().sd_nrm2sq_dev(m.ctx.h, code, x.data_ptr(), self.n_local, C.byref(loc)), m.ctx.h)
         return float(self._allreduce([loc.value], x.device, group)[0]) ** 0.5
+
+
+def kpm_sqw_replicas(psi0, model, q_list, omega, a, b, kpm_m=200, kernel="jackson", group=None):
+    """kpm_sqw (src/KPM_Sqw.jl:191-256) with the momenta dealt over the ranks instead of the vector: the q values are
+    independent (the reference threads over them, :218), so when the recursion's vectors fit one GPU (L <= 32) rank r runs
+    q_list[r::world] with the unsharded single-GPU recursion on its own replica of psi0 and the rows are combined with one
+    all-reduce of the Q x W matrix -- no data-path communication at all.  `model` is an UNSHARDED model on this rank's
+    GPU; every rank passes the same psi0 / q_list / omega and gets the full matrix back.  Without an initialised process
+    group it is the plain single-GPU kpm_sqw."""
+    import numpy as np
+    from .solvers import kpm_sqw
+    q_all = np.ascontiguousarray(q_list, dtype=np.float64)
+    world, rank, dist = 1, 0, None
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            world, rank = dist.get_world_size(group), dist.get_rank(group)
+        else:
+            dist = None
+    except ImportError:
+        dist = None
+    S = np.zeros((len(q_all), len(omega)))
+    mine = np.arange(rank, len(q_all), world)
+    if len(mine):
+        S[mine] = kpm_sqw(psi0, model, q_all[mine], omega, a=a, b=b, kpm_m=kpm_m, kernel=kernel)
+    if dist is not None and world > 1:
+        import torch
+        dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+        t = torch.from_numpy(S).to(dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)     # every row is non-zero on exactly one rank
+        S = t.cpu().numpy()
+    return S

@@ -127,3 +127,22 @@ def test_sharded_kpm_driver_matches_oracle(pkg, O, monkeypatch):
         want = O.compute_chebyshev_moments(r, phi, M, a, b)
         assert np.abs(op.kpm_moments(tphi, M, a, b) - want).max() <= 1e-13
         assert np.abs(op.kpm_moments(tphi, M, a, b, doubling=False) - want).max() <= 1e-13
+
+
+def test_kpm_q_replicas_two_processes_one_gpu():
+    """kpm_sqw_replicas (momenta dealt over the ranks, no data-path communication): two real processes sharing this GPU,
+    gloo for the final all-reduce; every rank must reproduce the single-process S(q,w) bit for bit."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(root, "profiles", "replicas_rehearsal.py")],
+                       cwd=root, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count("replicas == single: True") == 2
