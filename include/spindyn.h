@@ -280,11 +280,18 @@ int sd_fill_randn_local_dev(sd_ctx *ctx, const sd_model *m, int dtype, void *x_d
 /* Sharded apply with the imported partner tiles in a SEPARATE halo buffer (n_halo elements, filled by the exchange):
  * vectors then hold exactly n_local elements and one halo buffer serves every vector of a recursion.
  * epilogue: 0 out = H psi; 1 out = (H psi - b psi)/a; 2 fused Chebyshev term (ComplexF64; phi_prev, psi_t as in
- * sd_cheb_step_dev).  part: 0 all tiles; 1 only the interior tiles (every hop partner owned: reads no halo, so it
+ * sd_cheb_step_dev); 3 recurrence only, out = 2 (H psi - b psi)/a - phi_prev (psi_t untouched).  part: 0 all tiles; 1 only the interior tiles (every hop partner owned: reads no halo, so it
  * can run while the exchange is in flight); 2 only the boundary tiles.  All pointers are device pointers. */
 int sd_apply_sharded_dev(sd_ctx *ctx, const sd_model *m, int dtype, void *out_dev, const void *psi_dev,
                          const void *halo_dev, int64_t n_local, int epilogue, double a, double b,
                          double c_re, double c_im, const void *phi_prev_dev, void *psi_t_dev, int part);
+/* The pair form of the Chebyshev term (src/TimeEvolution/Chebyshev.jl:110-121): sd_apply_sharded_dev with epilogue 3
+ * computes phi_k = 2 H~ phi_{k-1} - phi_{k-2} without touching psi_t; this call then computes
+ * out = phi_{k+1} = 2 H~ psi - phi_prev (psi = phi_k) and psi_t += c0*phi_k; psi_t += c*phi_{k+1}, in that order --
+ * the same bits as one accumulation per term, with psi_t read and written once per two terms. */
+int sd_apply_sharded_cheb2_dev(sd_ctx *ctx, const sd_model *m, void *out, const void *psi, const void *halo, int64_t n_local,
+                               double a, double b, double c0_re, double c0_im, double c_re, double c_im,
+                               const void *phi_prev, void *psi_t, int part);
 int sd_model_shard_info(const sd_model *m, sd_shard_info *out);
 int sd_model_shard_slabs(const sd_model *m, sd_slab *recv_out, sd_slab *send_out);
 

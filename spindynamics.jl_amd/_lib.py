@@ -107,6 +107,7 @@ PROTOTYPES = {
     "sd_fill_randn_host": (_i, [_dp, _i64, _u64, _u64]),
     "sd_model_set_shard": (_i, [_vp, _i, _i]),
     "sd_apply_sharded_dev": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i64, _i, _d, _d, _d, _d, _vp, _vp, _i]),
+    "sd_apply_sharded_cheb2_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _d, _d, _d, _d, _d, _d, _vp, _vp, _i]),
     "sd_kpm_step_sharded_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _d, _d, _i, _dp]),
     "sd_model_set_shard_mode": (_i, [_vp, _i, _i, _i]),
     "sd_model_local_tiles": (_i, [_vp, _i64p, _i64p, _ip]),

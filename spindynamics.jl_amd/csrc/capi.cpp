@@ -349,9 +349,26 @@ int sd_apply_sharded_dev(sd_ctx *ctx, const sd_model *m, int dtype, void *out, c
     case 2:
       if (dtype != SD_C128 || !phi_prev || !psi_t) return sd_set_err(ctx, SD_EARG, "Chebyshev epilogue needs ComplexF64 phi_prev and psi_t");
       epi = SD_EPI_CHEB; break;
+    case 3:
+      if (!phi_prev) return sd_set_err(ctx, SD_EARG, "recurrence epilogue needs phi_prev");
+      epi = SD_EPI_RECUR; break;
     default: return sd_set_err(ctx, SD_EARG, "unknown epilogue");
   }
   return sd_launch_apply(ctx, m, dtype, out, psi, epi, ea, part);
+}
+
+int sd_apply_sharded_cheb2_dev(sd_ctx *ctx, const sd_model *m, void *out, const void *psi, const void *halo, int64_t n_local,
+                               double a, double b, double c0_re, double c0_im, double c_re, double c_im,
+                               const void *phi_prev, void *psi_t, int part) {
+  int rc = check_apply_args(ctx, m, SD_C128, out, psi, n_local);
+  if (rc) return rc;
+  if (n_local != m->n_local) return sd_set_err(ctx, SD_EDIM, "vector length does not match the local basis dimension");
+  if (part < 0 || part > 2) return sd_set_err(ctx, SD_EARG, "part must be 0 (all), 1 (interior) or 2 (boundary)");
+  if (m->n_halo > 0 && !halo && part != 1) return sd_set_err(ctx, SD_EARG, "this shard needs a halo buffer");
+  if (!phi_prev || !psi_t) return sd_set_err(ctx, SD_EARG, "null vector");
+  sd_epi_args ea; ea.a = a; ea.b = b; ea.c0_re = c0_re; ea.c0_im = c0_im; ea.c_re = c_re; ea.c_im = c_im;
+  ea.prev = phi_prev; ea.accv = psi_t; ea.halo = halo;
+  return sd_launch_apply(ctx, m, SD_C128, out, psi, SD_EPI_CHEB2, ea, part);
 }
 
 int sd_apply_rescaled_dev(sd_ctx *ctx, const sd_model *m, int dtype, void *out, const void *psi, int64_t n, double a,

@@ -103,6 +103,18 @@ __device__ __forceinline__ void epilogue<1>(int epi, const sd_epi_args &ea, int6
       sums.s0 += ph * o;
       sums.s1 += o * o;
     } break;
+    case SD_EPI_RECUR:
+      out[row] = 2.0 * ((acc - ea.b * own) / ea.a) - ((const double *)ea.prev)[row];
+      break;
+    case SD_EPI_CHEB2: {
+      double o = 2.0 * ((acc - ea.b * own) / ea.a) - ((const double *)ea.prev)[row];
+      out[row] = o;
+      double *pt = (double *)ea.accv;
+      double t = pt[row];
+      t += ea.c0_re * own;
+      t += ea.c_re * o;
+      pt[row] = t;
+    } break;
     default: {  // SD_EPI_CHEB on real vectors: real accumulate with real coefficient
       double o = 2.0 * ((acc - ea.b * own) / ea.a) - ((const double *)ea.prev)[row];
       out[row] = o;
@@ -144,6 +156,24 @@ __device__ __forceinline__ void epilogue<2>(int epi, const sd_epi_args &ea, int6
       double2 ph = ea.phi ? ((const double2 *)ea.phi)[row] : own;
       sums.s0 += ph.x * o.x + ph.y * o.y;
       sums.s1 += o.x * o.x + o.y * o.y;
+    } break;
+    case SD_EPI_RECUR: {
+      double2 pv = ((const double2 *)ea.prev)[row];
+      o2[row] = make_double2(2.0 * ((acc.x - ea.b * own.x) / ea.a) - pv.x, 2.0 * ((acc.y - ea.b * own.y) / ea.a) - pv.y);
+    } break;
+    case SD_EPI_CHEB2: {  // two Chebyshev terms per pass over psi_t: the deferred c0*phi_k (phi_k = this apply's input) and
+      // c*phi_{k+1}, added in that order with the arithmetic of two SD_EPI_CHEB passes (bit-identical), one psi_t read-modify-write
+      double2 pv = ((const double2 *)ea.prev)[row];
+      double2 o = make_double2(2.0 * ((acc.x - ea.b * own.x) / ea.a) - pv.x,
+                               2.0 * ((acc.y - ea.b * own.y) / ea.a) - pv.y);
+      o2[row] = o;
+      double2 *pt = (double2 *)ea.accv;
+      double2 t = pt[row];
+      t.x += ea.c0_re * own.x - ea.c0_im * own.y;
+      t.y += ea.c0_re * own.y + ea.c0_im * own.x;
+      t.x += ea.c_re * o.x - ea.c_im * o.y;
+      t.y += ea.c_re * o.y + ea.c_im * o.x;
+      pt[row] = t;
     } break;
     default: {  // SD_EPI_CHEB  (src/TimeEvolution/Chebyshev.jl:112-117)
       double2 pv = ((const double2 *)ea.prev)[row];

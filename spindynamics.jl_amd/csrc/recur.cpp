@@ -524,10 +524,24 @@ extern "C" int sd_chebyshev_evolve(sd_ctx *ctx, const sd_model *m, const void *p
   RC(sd_launch_apply(ctx, m, SD_C128, pcur, pprev, SD_EPI_RESCALE, ea));                  // :93
   RC(sd_k_cheb_init(ctx, pt.p, pprev, pcur, n, c[0], c[1], cheb_n >= 2 ? c[2] : 0.0, cheb_n >= 2 ? c[3] : 0.0,
                     cheb_n >= 2));                                                        // :96-102
-  for (int k = 2; k <= cheb_n - 1; ++k) {                                                 // :110-121, one fused pass per term
-    ea.prev = pprev; ea.accv = pt.p; ea.c_re = c[2 * k]; ea.c_im = c[2 * k + 1];
+  // :110-121, one fused pass per term.  Terms are taken in pairs: the first of a pair only advances the recurrence, the
+  // second adds both terms to psi_t in order (c_k phi_k is exact in the apply's input vector), so psi_t is read and
+  // written once per two terms -- same bits as one accumulation per term, 72 instead of 80 B/row per term.
+  int k = 2;
+  ea.accv = pt.p;
+  if ((cheb_n - 2) % 2 == 1) {
+    ea.prev = pprev; ea.c_re = c[2 * k]; ea.c_im = c[2 * k + 1];
     RC(sd_launch_apply(ctx, m, SD_C128, pnext, pcur, SD_EPI_CHEB, ea));
     double *t = pprev; pprev = pcur; pcur = pnext; pnext = t;
+    ++k;
+  }
+  for (; k + 1 <= cheb_n - 1; k += 2) {
+    ea.prev = pprev;
+    RC(sd_launch_apply(ctx, m, SD_C128, pnext, pcur, SD_EPI_RECUR, ea));                  // phi_k
+    { double *t = pprev; pprev = pcur; pcur = pnext; pnext = t; }
+    ea.prev = pprev; ea.c0_re = c[2 * k]; ea.c0_im = c[2 * k + 1]; ea.c_re = c[2 * k + 2]; ea.c_im = c[2 * k + 3];
+    RC(sd_launch_apply(ctx, m, SD_C128, pnext, pcur, SD_EPI_CHEB2, ea));                  // phi_{k+1}; psi_t += c_k phi_k + c_{k+1} phi_{k+1}
+    { double *t = pprev; pprev = pcur; pcur = pnext; pnext = t; }
   }
   RC(d2h(ctx, psit, pt.p, 2 * n));
   return SD_OK;

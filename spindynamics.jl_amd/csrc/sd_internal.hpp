@@ -158,11 +158,14 @@ enum sd_epilogue {
   SD_EPI_CHEB = 2,      // out = 2*(H psi - b psi)/a - prev ; acc_vec += c*out
   SD_EPI_KPM = 3,       // out = 2*(H psi - b psi)/a - prev ; partial sums Re<phi|out>, |out|^2
   SD_EPI_DOT = 4,       // out = H psi ; partial sums <psi|out> (re, im)
-  SD_EPI_RESCALE_DOT = 5  // out = (H psi - b psi)/a ; partial sums Re<phi|out>, |out|^2
+  SD_EPI_RESCALE_DOT = 5,  // out = (H psi - b psi)/a ; partial sums Re<phi|out>, |out|^2
+  SD_EPI_RECUR = 6,     // out = 2*(H psi - b psi)/a - prev            (Chebyshev term whose accumulation is deferred)
+  SD_EPI_CHEB2 = 7      // out = 2*(H psi - b psi)/a - prev ; acc_vec += c0*psi ; acc_vec += c*out   (two terms, one pass over acc_vec)
 };
 struct sd_epi_args {
   double a = 1.0, b = 0.0;
   double c_re = 0.0, c_im = 0.0;
+  double c0_re = 0.0, c0_im = 0.0;   // CHEB2: coefficient of the deferred previous term (= the apply's input vector)
   const void *prev = nullptr;   // phi_prev / v_prev
   void *accv = nullptr;         // psi_t (CHEB)
   const void *phi = nullptr;    // KPM reference vector

@@ -125,7 +125,7 @@ class ShardedOperator:
             req.wait()
         return halo
 
-    def _launch(self, out, psi, halo, epilogue, a=1.0, b=0.0, c=0j, prev=None, acc=None, part=0):
+    def _launch(self, out, psi, halo, epilogue, a=1.0, b=0.0, c=0j, prev=None, acc=None, part=0, c0=0j):
         import torch
         if self.n_local == 0:          # a rank may own no tile when there are fewer tiles than ranks
             return out
@@ -133,6 +133,13 @@ class ShardedOperator:
         m.ctx.set_stream(torch.cuda.current_stream(psi.device).cuda_stream)
         code = _lib.SD_C128 if psi.is_complex() else _lib.SD_F64
         c = complex(c)
+        if epilogue == 4:              # second term of a Chebyshev pair: psi_t += c0*psi; psi_t += c*out
+            c0 = complex(c0)
+            check(lib().sd_apply_sharded_cheb2_dev(m.ctx.h, m.h, out.data_ptr(), psi.data_ptr(),
+                                                   halo.data_ptr() if self.n_halo else None, self.n_local, float(a), float(b),
+                                                   c0.real, c0.imag, c.real, c.imag, prev.data_ptr(), acc.data_ptr(), part),
+                  m.ctx.h)
+            return out
         check(lib().sd_apply_sharded_dev(m.ctx.h, m.h, code, out.data_ptr(), psi.data_ptr(),
                                          halo.data_ptr() if self.n_halo else None, self.n_local, epilogue,
                                          float(a), float(b), c.real, c.imag,
@@ -183,9 +190,19 @@ class ShardedOperator:
         acc += complex(c[0]) * prev
         if cheb_n >= 2:
             acc += complex(c[1]) * cur
-        for k in range(2, int(cheb_n)):
+        # terms in pairs: the first of a pair only advances the recurrence (epilogue 3), the second adds both terms to psi_t
+        # in order (sd_apply_sharded_cheb2_dev) -- same bits as one accumulation per term, psi_t touched half as often
+        k = 2
+        if int(cheb_n) > 2 and (int(cheb_n) - 2) % 2 == 1:
             self.cheb_step(nxt, cur, prev, acc, a, b, complex(c[k]), group)
             prev, cur, nxt = cur, nxt, prev
+            k += 1
+        while k + 1 <= int(cheb_n) - 1:
+            self._apply(nxt, cur, group, 3, a=a, b=b, prev=prev)
+            prev, cur, nxt = cur, nxt, prev
+            self._apply(nxt, cur, group, 4, a=a, b=b, c=complex(c[k + 1]), c0=complex(c[k]), prev=prev, acc=acc)
+            prev, cur, nxt = cur, nxt, prev
+            k += 2
         return acc
 
     # ---- KPM on a sharded state (BASELINE config 5: L=36 over 8 GPUs) ----

@@ -232,3 +232,37 @@ def test_fused_epilogues_vs_unfused_device_ops(pkg, O):
     out = torch.empty_like(dv)
     pkg.apply_H(out, dv, m)
     assert np.array_equal(out.cpu().numpy(), O.apply_H(r, v))
+
+
+@pytest.mark.parametrize("cheb_n", [1, 2, 3, 4, 5, 8, 13])
+def test_chebyshev_pairing_is_bit_identical_to_one_term_per_pass(pkg, cheb_n):
+    """sd_chebyshev_evolve and the sharded driver take the terms in pairs (RECUR + CHEB2 epilogues: psi_t is read and
+    written once per two terms).  Both must give the same BITS as one fused cheb_step per term (the reference's loop,
+    src/TimeEvolution/Chebyshev.jl:110-121), for even and odd numbers of terms."""
+    import torch
+    L, nup = 14, 7
+    m = pkg.XXZChain(L, nup=nup, Jz=0.7)
+    psi0 = cvec(m.N, 21)
+    psi0 /= np.linalg.norm(psi0)
+    dt, Eb = 0.37, (-7.5, 4.0)
+    a, b = (Eb[1] - Eb[0]) / (2 * 0.9999), (Eb[1] + Eb[0]) / 2
+    c = pkg.chebyshev_coeffs(cheb_n, a, b, dt)
+    prev = torch.from_numpy(psi0).cuda()
+    cur, nxt = torch.empty_like(prev), torch.empty_like(prev)
+    pkg.apply_rescaled_H(cur, prev, pkg.apply_H, m, a, b)
+    acc = torch.zeros_like(prev)
+    acc += complex(c[0]) * prev
+    if cheb_n >= 2:
+        acc += complex(c[1]) * cur
+    for k in range(2, cheb_n):
+        pkg.cheb_step(nxt, cur, prev, acc, m, a, b, complex(c[k]))
+        prev, cur, nxt = cur, nxt, prev
+    want = acc.cpu().numpy()
+    got = pkg.chebyshev_time_evolve(psi0, dt, pkg.apply_H, m, cheb_n=cheb_n, Ebounds=Eb)
+    got_sharded = pkg.ShardedOperator(m, 0, 1).chebyshev_time_evolve(torch.from_numpy(psi0).cuda(), dt, cheb_n=cheb_n,
+                                                                   Ebounds=Eb).cpu().numpy()
+    # the sharded driver forms the first two terms with the same torch operations as above: bit for bit.  The C recursion
+    # forms them in k_cheb_init (unfused multiply-add; torch may contract its complex product), so its psi_t can start an
+    # ulp away and is compared to 1e-15 absolute (|psi_t| <= 1); the pairing itself is what the exact comparison pins.
+    assert np.array_equal(got_sharded, want)
+    assert np.abs(got - want).max() <= 1e-15
