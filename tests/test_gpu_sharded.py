@@ -14,19 +14,37 @@ pytestmark = pytest.mark.gpu
                                         # boundary part are each several launches with 64/128/256-thread workgroups
                                         (20, 10, 4, -12), (22, 9, 3, -11), (21, 10, 8, -12)])
 def test_virtual_shards_bit_identical(pkg, L, nup, P, ls, mode, monkeypatch):
-    import torch
     if ls < 0:
         monkeypatch.setenv("SD_LEN_CLASSES", "2")
         ls = -ls
     monkeypatch.setenv("SD_SUFFIX_BITS", str(ls))
-    full = pkg.XXZChain(L, nup=nup)
+    check_virtual_shards(pkg, L, nup, P, mode, {})
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_virtual_shards_random(pkg, seed, monkeypatch):
+    """Seeded random sector, rank count, tile size, ownership mode, boundary condition and couplings."""
+    rng = np.random.default_rng(500 + seed)
+    L = int(rng.integers(10, 21))
+    nup = int(rng.integers(max(1, L // 2 - 3), min(L - 1, L // 2 + 3) + 1))
+    P = int(rng.integers(2, 9))
+    monkeypatch.setenv("SD_SUFFIX_BITS", str(int(rng.integers(4, 13))))
+    monkeypatch.setenv("SD_LEN_CLASSES", str(int(rng.choice([1, 2]))))
+    kw = {"Jxy": float(rng.choice([1.0, 0.7])), "Jz": float(rng.normal()), "hz": float(rng.choice([0.0, 0.3])),
+          "boundary": str(rng.choice(["open", "periodic"]))}
+    check_virtual_shards(pkg, L, nup, P, str(rng.choice(["range", "class"])), kw, need_interior=False)
+
+
+def check_virtual_shards(pkg, L, nup, P, mode, kw, need_interior=True):
+    import torch
+    full = pkg.XXZChain(L, nup=nup, **kw)
     rng = np.random.default_rng(L * P)
     psi = rng.standard_normal(full.N) + 1j * rng.standard_normal(full.N)
     want = np.empty_like(psi)
     pkg.apply_H(want, psi, full)
     ops, bufs = [], []
     for r in range(P):
-        m = pkg.XXZChain(L, nup=nup)
+        m = pkg.XXZChain(L, nup=nup, **kw)
         op = pkg.ShardedOperator(m, r, P, mode=mode)
         buf = torch.from_numpy(psi[m.local_rows()].copy()).cuda()
         op.halo(buf).fill_(float("nan"))
@@ -54,7 +72,7 @@ def test_virtual_shards_bit_identical(pkg, L, nup, P, ls, mode, monkeypatch):
             ops[r]._launch(out, bufs[r], ops[r].halo(bufs[r]), 0, part=2)
         n_int += ops[r].n_interior_tiles
         got[ops[r].model.local_rows()] = out.cpu().numpy()
-    assert n_int > 0 or L <= 14          # (two-tile plans have no interior tile)
+    assert n_int > 0 or L <= 14 or not need_interior          # (two-tile plans have no interior tile)
     assert np.array_equal(got, want)
     assert sum(o.n_local for o in ops) == full.N
 
