@@ -87,10 +87,12 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
+        import datetime
+        tmo = datetime.timedelta(seconds=int(os.environ.get("SD_BENCH_DIST_TIMEOUT", "240")))   # a stuck exchange aborts, never hangs
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=tmo)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=tmo)
 
     L, nup = args.L, args.L // 2
     tdtype = torch.complex128 if args.dtype == "c128" else torch.float64
