@@ -880,6 +880,10 @@ int so_lanczos_sqw(const so_model *m, int nc, const double *psi0, const double *
   double *phi = (double *)malloc(sizeof(double) * 2 * N);
   int mm = lanc_m < N ? lanc_m : (int)N;
   double *alpha = (double *)malloc(sizeof(double) * mm), *beta = (double *)malloc(sizeof(double) * mm);
+  if (N < 1 || !psic || !tmp || !phi || !alpha || !beta) {
+    free(psic); free(tmp); free(phi); free(alpha); free(beta);
+    return SO_EARG;
+  }
   for (int64_t i = 0; i < N; ++i) { psic[2 * i] = psi0[nc * i]; psic[2 * i + 1] = nc == 2 ? psi0[2 * i + 1] : 0.0; }
   so_apply_H(m, 2, tmp, psic, N);                                      /* :58 */
   /* E0 = real(dot(conj(psi0c), tmp)) = Re sum psi_i * tmp_i  (:59, sic) */
