@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 
 #include "device_common.hpp"
@@ -759,7 +760,16 @@ int sd_launch_apply(sd_ctx *ctx, const sd_model *m, int dtype, void *out, const 
         if (cnt <= 0) continue;
         const int cls = m->seg_cls[sg];
         const int seg_max = std::min(max_len, (64 << cls) * 4);
-        const size_t shmem = (size_t)(seg_max + 1) * esz + 16 * SD_BIN_STRIDE * sizeof(int) + 32 * sizeof(double) + 16;
+        size_t shmem = (size_t)(seg_max + 1) * esz + 16 * SD_BIN_STRIDE * sizeof(int) + 32 * sizeof(double) + 16;
+        {   // experiment knob: SD_LDS_MIN_KB_<cls> raises the LDS request of a class, i.e. lowers its workgroups per CU
+          static int min_kb[SD_N_LEN_CLASS] = {-1, -1, -1, -1, -1};
+          if (min_kb[cls] < 0) {
+            char name[32]; snprintf(name, sizeof(name), "SD_LDS_MIN_KB_%d", cls);
+            const char *e = getenv(name);
+            min_kb[cls] = e ? atoi(e) : 0;
+          }
+          if ((size_t)min_kb[cls] * 1024 > shmem) shmem = (size_t)min_kb[cls] * 1024;
+        }
         dm.tile_off = m->seg_off[sg];
         if (dtype == SD_C128)
           rc = m->hop_pow2 ? launch_tiled<2, true>(ctx, dm, cnt, cls, shmem, (double *)out, (const double *)psi, epi, ea, seg_max)
