@@ -146,14 +146,18 @@ def main():
         src, dst = dst, src
     sync()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # per-step device times (median / min)
     t0 = time.perf_counter()
     ev0.record()
-    for _ in range(args.steps):
+    marks[0].record()
+    for k in range(args.steps):
         op.apply(dst, src)
         src, dst = dst, src
+        marks[k + 1].record()
     ev1.record()
     sync()
     t1 = time.perf_counter()
+    step_ms = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps))
     elapsed = t1 - t0
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
@@ -195,6 +199,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
+            "ms_per_step_median": step_ms[len(step_ms) // 2], "ms_per_step_min": step_ms[0],   # rank 0, device time per step
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
