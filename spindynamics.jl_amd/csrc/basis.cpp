@@ -225,6 +225,15 @@ int sd_build_plan(sd_model *m, int rank, int nranks, std::string &err) {
 
   const int L = m->L;
   int LS = std::min(L, suffix_bits_from_env());
+  if (m->nup >= 0) {
+    // the largest workgroup (1024 threads x 4 rows) must hold the longest tile, C(LS, t) over the feasible suffix fillings t
+    auto longest = [&](int ls) {
+      int64_t mx = 0;
+      for (int t = std::max(0, m->nup - (L - ls)); t <= std::min(ls, m->nup); ++t) mx = std::max(mx, B(m, ls, t));
+      return mx;
+    };
+    while (LS > 2 && longest(LS) > 4096) --LS;
+  }
   int p = L - LS;
   if (m->nup < 0 || p > SD_MAX_PREFIX_BITS) {
     // generic (untiled) path: per-row rank/unrank on device

@@ -99,3 +99,17 @@ def test_host_pointer_applies_reuse_and_release_staging(pkg, O):
             assert np.array_equal(out, O.apply_H(r, psi))
         if L == 16 and nup == 8:
             ctx.release_scratch()
+
+
+@pytest.mark.parametrize("ls", ["13", "14", "15"])
+def test_large_suffix_tiles(pkg, O, ls, monkeypatch):
+    """SD_SUFFIX_BITS up to 15: 512- and 1024-thread workgroups; LS is lowered on the host when the longest tile (C(15,7) =
+    6435 rows) would not fit the largest workgroup (4096 rows)."""
+    monkeypatch.setenv("SD_SUFFIX_BITS", ls)
+    for (L, nup) in [(16, 8), (18, 2), (17, 8)]:
+        m = pkg.XXZChain(L, nup=nup, Jz=0.3)
+        r = O.XXZChain(L, nup=nup, Jz=0.3)
+        psi = np.random.default_rng(L).standard_normal(m.N) + 1j * np.random.default_rng(L + 1).standard_normal(m.N)
+        out = np.empty_like(psi)
+        pkg.apply_H(out, psi, m)
+        assert np.array_equal(out, O.apply_H(r, psi))
