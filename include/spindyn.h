@@ -73,8 +73,11 @@ int sd_ctx_set_stream(sd_ctx *ctx, void *hip_stream);
  * mu_2n = 2<v_n|v_n> - mu_0, mu_2n+1 = 2Re<v_n|v_n+1> - mu_1 (v_n = T_n(H~)phi); on == 0 runs the reference's loop
  * (src/KPM_Sqw.jl:103-124), one moment <phi|v_k> per apply.  Same moments up to rounding. */
 int sd_ctx_set_kpm_doubling(sd_ctx *ctx, int on);
-/* A context keeps the device staging buffers of the host-pointer operator calls (sd_apply, sd_apply_rescaled: two
- * vectors) and its reduction scratch between calls; this frees them (they are re-created on demand). */
+/* A context keeps between calls: the device staging buffers of the host-pointer operator calls (sd_apply,
+ * sd_apply_rescaled: two vectors), its reduction scratch, and the work vectors of the recursion-level calls (a pool of at
+ * most SD_POOL_MAX_GB = 96 GB by default: hipMalloc of one 9.6 GB vector at L=32 takes 0.4-0.5 s, as long as twenty
+ * applies -- the role of the reference's `workspace` argument, src/TimeEvolution/Chebyshev.jl:61-66).  This call frees all
+ * of them; they are re-created on demand. */
 int sd_ctx_release_scratch(sd_ctx *ctx);
 int sd_ctx_synchronize(sd_ctx *ctx);
 /* last error text of this context ("" if none); valid until the next call */

@@ -58,3 +58,10 @@ if 4 in which:
     dt = time.time() - t0
     print(json.dumps({"config": 4, "what": "time_evolve(:chebyshev, cheb_n=100), L=32, host psi0 in / psi_t out (2 x 9.6 GB over PCIe)",
                       "N": m.N, "seconds": dt, "norm": float(np.linalg.norm(out))}), flush=True)
+    # time stepping: further calls reuse the context's work vectors (and the output array)
+    more = []
+    for _ in range(2):
+        t0 = time.time()
+        out = pkg.time_evolve(m, out, 0.5, method="chebyshev", cheb_n=100, Ebounds=(-14.5, 8.5))
+        more.append(time.time() - t0)
+    print(json.dumps({"config": 4, "what": "... two further steps of the same evolution (work vectors reused)", "seconds": more}), flush=True)

@@ -1,6 +1,7 @@
 // C ABI: contexts, models, operator-level entry points (include/spindyn.h).
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -10,6 +11,46 @@
 int sd_set_err(sd_ctx *ctx, int code, const std::string &msg) {
   if (ctx) ctx->err = msg;
   return code;
+}
+
+int sd_pool_take(sd_ctx *ctx, size_t bytes, void **out, size_t *got) {
+  if (bytes == 0) bytes = 8;
+  int best = -1;
+  for (int i = 0; i < (int)ctx->pool_free.size(); ++i) {
+    const size_t sz = ctx->pool_free[i].second;
+    if (sz >= bytes && sz <= 2 * bytes && (best < 0 || sz < ctx->pool_free[best].second)) best = i;
+  }
+  if (best >= 0) {
+    *out = ctx->pool_free[best].first; *got = ctx->pool_free[best].second;
+    ctx->pool_free.erase(ctx->pool_free.begin() + best);
+    return SD_OK;
+  }
+  hipError_t e = hipMalloc(out, bytes);
+  if (e != hipSuccess) {                       // make room: drop what the pool still holds, then try once more
+    (void)hipGetLastError();
+    sd_pool_release(ctx);
+    e = hipMalloc(out, bytes);
+  }
+  if (e != hipSuccess) { *out = nullptr; return sd_set_err(ctx, SD_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e)); }
+  *got = bytes;
+  return SD_OK;
+}
+
+void sd_pool_give(sd_ctx *ctx, void *p, size_t bytes) {
+  if (!p) return;
+  static const size_t cap = [] {               // bytes the pool may hold (SD_POOL_MAX_GB, default 96; 0 disables the pool)
+    const char *e = getenv("SD_POOL_MAX_GB");
+    return (size_t)((e ? atof(e) : 96.0) * 1e9);
+  }();
+  size_t held = 0;
+  for (auto &b : ctx->pool_free) held += b.second;
+  if (bytes < ((size_t)64 << 20) || held + bytes > cap) { (void)hipFree(p); return; }   // small blocks are cheap to re-create
+  ctx->pool_free.emplace_back(p, bytes);
+}
+
+void sd_pool_release(sd_ctx *ctx) {
+  for (auto &b : ctx->pool_free) (void)hipFree(b.first);
+  ctx->pool_free.clear();
 }
 
 int sd_ensure_partials(sd_ctx *ctx, size_t doubles) {
@@ -120,6 +161,7 @@ void sd_ctx_destroy(sd_ctx *c) {
   if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
   if (c->d_partials) (void)hipFree(c->d_partials);
   for (void *b : c->stage) if (b) (void)hipFree(b);
+  sd_pool_release(c);
   if (c->d_scalars) (void)hipFree(c->d_scalars);
   if (c->h_scalars) (void)hipHostFree(c->h_scalars);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -150,6 +192,7 @@ int sd_ctx_release_scratch(sd_ctx *ctx) {
   }
   if (ctx->d_partials) (void)hipFree(ctx->d_partials);
   ctx->d_partials = nullptr; ctx->partials_cap = 0;
+  sd_pool_release(ctx);
   return SD_OK;
 }
 

@@ -21,17 +21,25 @@
 
 namespace {
 
-struct DBuf {
+struct DBuf {   // device work vector, taken from / returned to the context's pool
   double *p = nullptr;
+  sd_ctx *owner = nullptr;
+  size_t bytes = 0;
   DBuf() = default;
   DBuf(const DBuf &) = delete;
   DBuf &operator=(const DBuf &) = delete;
-  ~DBuf() { if (p) (void)hipFree(p); }
+  ~DBuf() { release(); }
+  void release() {
+    if (p) sd_pool_give(owner, p, bytes);
+    p = nullptr; bytes = 0;
+  }
   int alloc(sd_ctx *ctx, int64_t doubles) {
-    if (p) { (void)hipFree(p); p = nullptr; }
-    hipError_t e = hipMalloc((void **)&p, sizeof(double) * (size_t)std::max<int64_t>(doubles, 1));
-    if (e != hipSuccess) return sd_set_err(ctx, SD_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
-    return SD_OK;
+    release();
+    owner = ctx;
+    void *q = nullptr;
+    int rc = sd_pool_take(ctx, sizeof(double) * (size_t)std::max<int64_t>(doubles, 1), &q, &bytes);
+    p = (double *)q;
+    return rc;
   }
 };
 

@@ -22,6 +22,7 @@
 #include <stdint.h>
 
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/spindyn.h"
@@ -51,6 +52,9 @@ struct sd_ctx {
   double *d_scalars = nullptr;  // 16 doubles, device
   double *h_scalars = nullptr;  // 16 doubles, pinned host
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // device work vectors of the recursion-level calls, kept between calls: hipMalloc of a 9.6 GB vector (L=32) takes
+  // 0.4-0.5 s, more than twenty applies.  sd_ctx_release_scratch / sd_ctx_destroy free them.
+  std::vector<std::pair<void *, size_t>> pool_free;
   void *stage[2] = {nullptr, nullptr};   // device staging of the host-pointer operator calls (sd_apply, ...), kept between calls
   size_t stage_cap[2] = {0, 0};
   int kpm_doubling = 1;     // sd_ctx_set_kpm_doubling: two Chebyshev moments per apply (default) or the reference's one
@@ -219,6 +223,10 @@ int sd_ensure_partials(sd_ctx *ctx, size_t doubles);
 
 // error helpers
 int sd_set_err(sd_ctx *ctx, int code, const std::string &msg);
+// work-vector pool of a context (see sd_ctx::pool_free): take a cached block of at least `bytes` (and at most twice that), or hipMalloc
+int sd_pool_take(sd_ctx *ctx, size_t bytes, void **out, size_t *got);
+void sd_pool_give(sd_ctx *ctx, void *p, size_t bytes);
+void sd_pool_release(sd_ctx *ctx);
 #define SD_HIP(ctx, call)                                                                       \
   do {                                                                                          \
     hipError_t e__ = (call);                                                                    \

@@ -101,6 +101,28 @@ def test_host_pointer_applies_reuse_and_release_staging(pkg, O):
             ctx.release_scratch()
 
 
+def test_recursion_work_vectors_are_pooled_and_released(pkg, monkeypatch):
+    """The recursion-level calls take their device vectors from the context's pool (blocks >= 64 MiB are kept between
+    calls): repeated calls, calls of other sizes and an explicit release in between must give identical results."""
+    L, nup = 24, 12                      # 2.7 M rows: 43 MB complex vectors (below the pooling threshold) ...
+    m = pkg.XXZChain(L, nup=nup)
+    psi0 = np.random.default_rng(3).standard_normal(m.N) + 0j
+    psi0 /= np.linalg.norm(psi0)
+    a = pkg.time_evolve(m, psi0, 0.2, method="chebyshev", cheb_n=12, Ebounds=(-11.0, 6.5))
+    big = pkg.XXZChain(26, nup=13)        # ... and 10.4 M rows: 166 MB vectors, pooled
+    phi = np.random.default_rng(4).standard_normal(big.N) + 0j
+    phi /= np.linalg.norm(phi)
+    r1 = pkg.time_evolve(big, phi, 0.2, method="chebyshev", cheb_n=6, Ebounds=(-12.0, 7.0))
+    r2 = pkg.time_evolve(big, phi, 0.2, method="chebyshev", cheb_n=6, Ebounds=(-12.0, 7.0))      # pooled vectors reused
+    k1 = pkg.time_evolve(big, phi, 0.2, method="krylov", kry_m=5)
+    m.ctx.release_scratch()
+    r3 = pkg.time_evolve(big, phi, 0.2, method="chebyshev", cheb_n=6, Ebounds=(-12.0, 7.0))
+    k2 = pkg.time_evolve(big, phi, 0.2, method="krylov", kry_m=5)
+    b = pkg.time_evolve(m, psi0, 0.2, method="chebyshev", cheb_n=12, Ebounds=(-11.0, 6.5))
+    assert np.array_equal(r1, r2) and np.array_equal(r1, r3) and np.array_equal(k1, k2) and np.array_equal(a, b)
+    assert abs(np.linalg.norm(r1) - 1) < 1e-3          # six Chebyshev terms: truncation, not rounding
+
+
 @pytest.mark.parametrize("ls", ["13", "14", "15"])
 def test_large_suffix_tiles(pkg, O, ls, monkeypatch):
     """SD_SUFFIX_BITS up to 15: 512- and 1024-thread workgroups; LS is lowered on the host when the longest tile (C(15,7) =
