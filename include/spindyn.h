@@ -167,6 +167,10 @@ int sd_krylov_evolve(sd_ctx *ctx, const sd_model *m, int dtype, const void *psi0
 /* chebyshev_time_evolve   src/TimeEvolution/Chebyshev.jl:61-124  (psi0 ComplexF64) */
 int sd_chebyshev_evolve(sd_ctx *ctx, const sd_model *m, const void *psi0_c128_host, int64_t n, double dt,
                         int cheb_n, double Emin, double Emax, void *psit_out_c128_host);
+/* the same on device vectors (ComplexF64, n elements): psi stays on the GPU between the steps of a time evolution.
+ * psit_dev may be psi0_dev (in place).  Returns after the stream has finished. */
+int sd_chebyshev_evolve_dev(sd_ctx *ctx, const sd_model *m, const void *psi0_c128_dev, int64_t n, double dt,
+                            int cheb_n, double Emin, double Emax, void *psit_out_c128_dev);
 /* compute_chebyshev_moments   src/KPM_Sqw.jl:95-128 */
 int sd_kpm_moments(sd_ctx *ctx, const sd_model *m, const void *phi_c128_host, int64_t n, int M,
                    double a, double b, double *mu_out);

@@ -6,7 +6,7 @@ The directory name contains a dot, so load the package through
 Importing does not need a GPU; creating a context / model does, and raises when
 the library or a device is missing -- there is no CPU fallback.
 """
-from ._lib import (ArgumentError, Context, DimensionMismatch, SpinDynError, ZeroNormError, default_context, lib,
+from ._lib import (ArgumentError, Context, check, DimensionMismatch, SpinDynError, ZeroNormError, default_context, lib,
                    LIB_PATH, PROTOTYPES)
 from .model import Model, XXZChain, build_model, long_range_hopping, momenta, nn_hopping
 from .hamiltonian import (Sz_q_vector, apply_H, apply_rescaled_H, bit_at, cheb_step, create_spin_operator, flip_bits,

@@ -516,18 +516,25 @@ extern "C" int sd_krylov_evolve(sd_ctx *ctx, const sd_model *m, int dtype, const
   return SD_OK;
 }
 
-extern "C" int sd_chebyshev_evolve(sd_ctx *ctx, const sd_model *m, const void *psi0, int64_t n, double dt, int cheb_n,
-                                   double Emin, double Emax, void *psit) {
+// chebyshev_time_evolve on device vectors: psi0_dev (c128, n elements) is read, psit_dev receives psi(t); they may be the
+// same buffer (psi0 is copied into the recursion's own vectors first).  host_in / host_out select the host-pointer form.
+static int chebyshev_evolve_core(sd_ctx *ctx, const sd_model *m, const void *psi0, bool host_in, int64_t n, double dt, int cheb_n,
+                                 double Emin, double Emax, void *psit, bool host_out) {
   RC(check_unsharded(ctx, m));
+  if (!psi0 || !psit) return sd_set_err(ctx, SD_EARG, "null vector");
   if (n != m->N) return sd_set_err(ctx, SD_EDIM, "vector length does not match the basis dimension");
   if (cheb_n < 1) return sd_set_err(ctx, SD_EARG, "cheb_n must be >= 1");               // :65
   const double a = (Emax - Emin) / (2 * 0.9999), b = (Emax + Emin) / 2;                   // :70-71
   std::vector<double> c(2 * (size_t)cheb_n);
   sd_chebyshev_coeffs(cheb_n, a, b, dt, c.data());
-  DBuf b0, b1, b2, pt;
-  RC(b0.alloc(ctx, 2 * n)); RC(b1.alloc(ctx, 2 * n)); RC(b2.alloc(ctx, 2 * n)); RC(pt.alloc(ctx, 2 * n));
+  DBuf b0, b1, b2, ptb;
+  RC(b0.alloc(ctx, 2 * n)); RC(b1.alloc(ctx, 2 * n)); RC(b2.alloc(ctx, 2 * n));
   double *pprev = b0.p, *pcur = b1.p, *pnext = b2.p;
-  RC(h2d(ctx, pprev, psi0, 2 * n));                                                       // :90
+  if (host_in) RC(h2d(ctx, pprev, psi0, 2 * n));                                          // :90
+  else RC(d2d(ctx, pprev, (const double *)psi0, 2 * n));
+  struct { double *p; } pt;                       // psi_t accumulates in the caller's device buffer when there is one
+  if (host_out) { RC(ptb.alloc(ctx, 2 * n)); pt.p = ptb.p; }
+  else pt.p = (double *)psit;
   sd_epi_args ea; ea.a = a; ea.b = b;
   RC(sd_launch_apply(ctx, m, SD_C128, pcur, pprev, SD_EPI_RESCALE, ea));                  // :93
   RC(sd_k_cheb_init(ctx, pt.p, pprev, pcur, n, c[0], c[1], cheb_n >= 2 ? c[2] : 0.0, cheb_n >= 2 ? c[3] : 0.0,
@@ -551,8 +558,19 @@ extern "C" int sd_chebyshev_evolve(sd_ctx *ctx, const sd_model *m, const void *p
     RC(sd_launch_apply(ctx, m, SD_C128, pnext, pcur, SD_EPI_CHEB2, ea));                  // phi_{k+1}; psi_t += c_k phi_k + c_{k+1} phi_{k+1}
     { double *t = pprev; pprev = pcur; pcur = pnext; pnext = t; }
   }
-  RC(d2h(ctx, psit, pt.p, 2 * n));
+  if (host_out) RC(d2h(ctx, psit, pt.p, 2 * n));
+  else SD_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the work vectors go back to the pool: nothing may still use them
   return SD_OK;
+}
+
+extern "C" int sd_chebyshev_evolve(sd_ctx *ctx, const sd_model *m, const void *psi0, int64_t n, double dt, int cheb_n,
+                                   double Emin, double Emax, void *psit) {
+  return chebyshev_evolve_core(ctx, m, psi0, true, n, dt, cheb_n, Emin, Emax, psit, true);
+}
+
+extern "C" int sd_chebyshev_evolve_dev(sd_ctx *ctx, const sd_model *m, const void *psi0_dev, int64_t n, double dt, int cheb_n,
+                                       double Emin, double Emax, void *psit_dev) {
+  return chebyshev_evolve_core(ctx, m, psi0_dev, false, n, dt, cheb_n, Emin, Emax, psit_dev, false);
 }
 
 extern "C" int sd_kpm_moments(sd_ctx *ctx, const sd_model *m, const void *phi, int64_t n, int M, double a, double b,

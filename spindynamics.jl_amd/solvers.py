@@ -13,7 +13,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import ArgumentError, DimensionMismatch, SD_C128, SD_F64, check, lib
-from .hamiltonian import apply_H
+from .hamiltonian import _bind_torch_stream, _is_torch, apply_H
 
 _dp = C.POINTER(C.c_double)
 
@@ -105,6 +105,17 @@ def chebyshev_time_evolve(psi0, dt, applyH, model, cheb_n=100, Ebounds=(-1.0, 1.
     """chebyshev_time_evolve(psi0, dt, applyH!, model; cheb_n, Ebounds) -- src/TimeEvolution/Chebyshev.jl:61-124.
     psi0 must be complex (the reference's workspace is typed by psi0 and receives complex coefficients)."""
     _need_apply(applyH)
+    if _is_torch(psi0):          # device-resident state: no PCIe per step of a time evolution
+        import torch
+        if psi0.dtype != torch.complex128:
+            raise ArgumentError("chebyshev_time_evolve needs a ComplexF64 psi0 (as the reference does)")
+        if int(cheb_n) < 1:
+            raise AssertionError("cheb_n must be >= 1")
+        _bind_torch_stream(model, psi0)
+        out = torch.empty_like(psi0)
+        check(lib().sd_chebyshev_evolve_dev(model.ctx.h, model.h, psi0.data_ptr(), len(psi0), float(dt), int(cheb_n),
+                                            float(Ebounds[0]), float(Ebounds[1]), out.data_ptr()), model.ctx.h)
+        return out
     if not np.iscomplexobj(psi0):
         raise ArgumentError("chebyshev_time_evolve needs a ComplexF64 psi0 (as the reference does)")
     if int(cheb_n) < 1:

@@ -266,3 +266,28 @@ def test_chebyshev_pairing_is_bit_identical_to_one_term_per_pass(pkg, cheb_n):
     # ulp away and is compared to 1e-15 absolute (|psi_t| <= 1); the pairing itself is what the exact comparison pins.
     assert np.array_equal(got_sharded, want)
     assert np.abs(got - want).max() <= 1e-15
+
+
+def test_chebyshev_evolve_device_resident(pkg):
+    """sd_chebyshev_evolve_dev: the state stays on the GPU between the steps of a time evolution.  Same bits as the
+    host-pointer call; in place (psit == psi0) allowed at the C level."""
+    import torch
+    L, nup = 14, 7
+    m = pkg.XXZChain(L, nup=nup, Jz=0.6)
+    psi0 = cvec(m.N, 33)
+    psi0 /= np.linalg.norm(psi0)
+    Eb = (-7.0, 4.0)
+    host = psi0.copy()
+    dev = torch.from_numpy(psi0).cuda()
+    for _ in range(3):                                     # three steps of dt = 0.2
+        host = pkg.chebyshev_time_evolve(host, 0.2, pkg.apply_H, m, cheb_n=25, Ebounds=Eb)
+        dev = pkg.chebyshev_time_evolve(dev, 0.2, pkg.apply_H, m, cheb_n=25, Ebounds=Eb)
+    assert isinstance(dev, torch.Tensor) and dev.is_cuda
+    assert np.array_equal(dev.cpu().numpy(), host)
+    # in place
+    z = torch.from_numpy(psi0).cuda()
+    m.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    pkg.check(pkg.lib().sd_chebyshev_evolve_dev(m.ctx.h, m.h, z.data_ptr(), m.N, 0.2, 25, Eb[0], Eb[1], z.data_ptr()), m.ctx.h)
+    assert np.array_equal(z.cpu().numpy(), pkg.chebyshev_time_evolve(psi0, 0.2, pkg.apply_H, m, cheb_n=25, Ebounds=Eb))
+    with pytest.raises(pkg.ArgumentError):
+        pkg.chebyshev_time_evolve(torch.ones(m.N, dtype=torch.float64, device="cuda"), 0.1, pkg.apply_H, m, Ebounds=Eb)
