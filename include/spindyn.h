@@ -164,6 +164,10 @@ int sd_lanczos_tridiag(sd_ctx *ctx, const sd_model *m, const void *v_c128_host, 
 /* krylov_time_evolve   src/TimeEvolution/Krylov.jl:136-192.  psit_out is ComplexF64. */
 int sd_krylov_evolve(sd_ctx *ctx, const sd_model *m, int dtype, const void *psi0_host, int64_t n,
                      double dt, int kry_m, void *psit_out_c128_host);
+/* the same on device vectors (psi0 of `dtype`, psit ComplexF64; psit may be a ComplexF64 psi0).  Returns after the stream
+ * has finished. */
+int sd_krylov_evolve_dev(sd_ctx *ctx, const sd_model *m, int dtype, const void *psi0_dev, int64_t n,
+                         double dt, int kry_m, void *psit_out_c128_dev);
 /* chebyshev_time_evolve   src/TimeEvolution/Chebyshev.jl:61-124  (psi0 ComplexF64) */
 int sd_chebyshev_evolve(sd_ctx *ctx, const sd_model *m, const void *psi0_c128_host, int64_t n, double dt,
                         int cheb_n, double Emin, double Emax, void *psit_out_c128_host);

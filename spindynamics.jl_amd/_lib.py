@@ -83,6 +83,7 @@ PROTOTYPES = {
     "sd_lanczos_groundstate": (_i, [_vp, _vp, _i, _d, _d, _dp, _u64, _dp, _dp, _ip]),
     "sd_lanczos_tridiag": (_i, [_vp, _vp, _vp, _i64, _i, _d, _dp, _dp, _ip, _dp]),
     "sd_krylov_evolve": (_i, [_vp, _vp, _i, _vp, _i64, _d, _i, _vp]),
+    "sd_krylov_evolve_dev": (_i, [_vp, _vp, _i, _vp, _i64, _d, _i, _vp]),
     "sd_chebyshev_evolve": (_i, [_vp, _vp, _vp, _i64, _d, _i, _d, _d, _vp]),
     "sd_chebyshev_evolve_dev": (_i, [_vp, _vp, _vp, _i64, _d, _i, _d, _d, _vp]),
     "sd_kpm_moments": (_i, [_vp, _vp, _vp, _i64, _i, _d, _d, _dp]),

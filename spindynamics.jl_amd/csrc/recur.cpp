@@ -458,9 +458,17 @@ extern "C" int sd_lanczos_tridiag(sd_ctx *ctx, const sd_model *m, const void *v,
   return tridiag_dev(ctx, m, vc.p, lanc_m, tol, alpha, beta, m_eff);
 }
 
-extern "C" int sd_krylov_evolve(sd_ctx *ctx, const sd_model *m, int dtype, const void *psi0, int64_t n, double dt,
-                                int kry_m, void *psit) {
+// krylov_time_evolve; on_dev: psi0 / psit are device vectors (psit ComplexF64; may alias a ComplexF64 psi0)
+static int krylov_evolve_core(sd_ctx *ctx, const sd_model *m, int dtype, const void *psi0, int64_t n, double dt, int kry_m,
+                              void *psit, bool on_dev) {
   RC(check_unsharded(ctx, m));
+  if (!psi0 || !psit) return sd_set_err(ctx, SD_EARG, "null vector");
+  auto emit = [&](const double *src) -> int {          // result to the caller
+    if (!on_dev) return d2h(ctx, psit, src, 2 * n);
+    RC(d2d(ctx, (double *)psit, src, 2 * n));
+    SD_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the work vectors go back to the pool: nothing may still use them
+    return SD_OK;
+  };
   if (n != m->N) return sd_set_err(ctx, SD_EDIM, "vector length does not match the basis dimension");
   if (dtype != SD_F64 && dtype != SD_C128) return sd_set_err(ctx, SD_EARG, "bad dtype");
   if (kry_m < 1) return sd_set_err(ctx, SD_EARG, "kry_m must be >= 1");
@@ -468,13 +476,14 @@ extern "C" int sd_krylov_evolve(sd_ctx *ctx, const sd_model *m, int dtype, const
   // all Krylov vectors are kept complex on the device; a real psi0 keeps exactly-zero imaginary parts
   std::vector<DBuf> V(kry_m);
   DBuf in, w;
-  RC(in.alloc(ctx, nc * n)); RC(w.alloc(ctx, 2 * n));
-  RC(h2d(ctx, in.p, psi0, nc * n));
+  RC(w.alloc(ctx, 2 * n));
+  const double *inp = (const double *)psi0;
+  if (!on_dev) { RC(in.alloc(ctx, nc * n)); RC(h2d(ctx, in.p, psi0, nc * n)); inp = in.p; }
   int rc = 0;
-  const double norm0 = norm_dev(ctx, in.p, nc * n, &rc); RC(rc);
+  const double norm0 = norm_dev(ctx, inp, nc * n, &rc); RC(rc);
   RC(V[0].alloc(ctx, 2 * n));
-  RC(sd_k_promote(ctx, V[0].p, in.p, nc, n));
-  if (norm0 == 0) { RC(d2h(ctx, psit, V[0].p, 2 * n)); return SD_OK; }                    // :145-147
+  RC(sd_k_promote(ctx, V[0].p, inp, nc, n));
+  if (norm0 == 0) return emit(V[0].p);                                                    // :145-147
   RC(sd_k_scale_div(ctx, V[0].p, V[0].p, 2 * n, norm0));                                  // :148
   std::vector<double> alr(kry_m, 0.0), beta(kry_m, 0.0);
   int m_eff = kry_m;
@@ -512,8 +521,17 @@ extern "C" int sd_krylov_evolve(sd_ctx *ctx, const sd_model *m, int dtype, const
   }
   const double nn = norm_dev(ctx, w.p, 2 * n, &rc); RC(rc);
   RC(sd_k_scale_div(ctx, w.p, w.p, 2 * n, nn));                                           // :190
-  RC(d2h(ctx, psit, w.p, 2 * n));
-  return SD_OK;
+  return emit(w.p);
+}
+
+extern "C" int sd_krylov_evolve(sd_ctx *ctx, const sd_model *m, int dtype, const void *psi0, int64_t n, double dt,
+                                int kry_m, void *psit) {
+  return krylov_evolve_core(ctx, m, dtype, psi0, n, dt, kry_m, psit, false);
+}
+
+extern "C" int sd_krylov_evolve_dev(sd_ctx *ctx, const sd_model *m, int dtype, const void *psi0_dev, int64_t n, double dt,
+                                    int kry_m, void *psit_dev) {
+  return krylov_evolve_core(ctx, m, dtype, psi0_dev, n, dt, kry_m, psit_dev, true);
 }
 
 // chebyshev_time_evolve on device vectors: psi0_dev (c128, n elements) is read, psit_dev receives psi(t); they may be the

@@ -94,6 +94,15 @@ def lanczos_tridiag(applyH, model, v, lanc_m=100, tol=1e-12):
 def krylov_time_evolve(psi0, dt, applyH, model, kry_m=30):
     """krylov_time_evolve(psi0, dt, applyH!, model; kry_m) -> psi(t) ComplexF64, normalised -- src/TimeEvolution/Krylov.jl:136-192"""
     _need_apply(applyH)
+    if _is_torch(psi0):          # device-resident state
+        import torch
+        if psi0.dtype not in (torch.float64, torch.complex128):
+            raise ArgumentError("vectors must be float64 or complex128")
+        _bind_torch_stream(model, psi0)
+        out = torch.empty(len(psi0), dtype=torch.complex128, device=psi0.device)
+        check(lib().sd_krylov_evolve_dev(model.ctx.h, model.h, SD_C128 if psi0.is_complex() else SD_F64, psi0.data_ptr(),
+                                         len(psi0), float(dt), int(kry_m), out.data_ptr()), model.ctx.h)
+        return out
     x, code = _vec(psi0)
     out = np.empty(len(x), dtype=np.complex128)
     check(lib().sd_krylov_evolve(model.ctx.h, model.h, code, x.ctypes.data, len(x), float(dt), int(kry_m), out.ctypes.data),

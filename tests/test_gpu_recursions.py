@@ -291,3 +291,22 @@ def test_chebyshev_evolve_device_resident(pkg):
     assert np.array_equal(z.cpu().numpy(), pkg.chebyshev_time_evolve(psi0, 0.2, pkg.apply_H, m, cheb_n=25, Ebounds=Eb))
     with pytest.raises(pkg.ArgumentError):
         pkg.chebyshev_time_evolve(torch.ones(m.N, dtype=torch.float64, device="cuda"), 0.1, pkg.apply_H, m, Ebounds=Eb)
+
+
+def test_krylov_evolve_device_resident(pkg):
+    """sd_krylov_evolve_dev: same bits as the host-pointer call, for real and complex device states, over several steps."""
+    import torch
+    m = pkg.XXZChain(14, nup=7, Jz=0.6)
+    psi0 = cvec(m.N, 34)
+    psi0 /= np.linalg.norm(psi0)
+    host, dev = psi0.copy(), torch.from_numpy(psi0).cuda()
+    for _ in range(3):
+        host = pkg.krylov_time_evolve(host, 0.3, pkg.apply_H, m, kry_m=12)
+        dev = pkg.krylov_time_evolve(dev, 0.3, pkg.apply_H, m, kry_m=12)
+    assert np.array_equal(dev.cpu().numpy(), host)
+    real0 = np.random.default_rng(2).standard_normal(m.N)
+    a = pkg.krylov_time_evolve(real0, 0.3, pkg.apply_H, m, kry_m=8)
+    b = pkg.krylov_time_evolve(torch.from_numpy(real0).cuda(), 0.3, pkg.apply_H, m, kry_m=8)
+    assert b.dtype == torch.complex128 and np.array_equal(b.cpu().numpy(), a)
+    z = torch.zeros(m.N, dtype=torch.complex128, device="cuda")          # zero state comes back unchanged (Krylov.jl:145-147)
+    assert float(pkg.krylov_time_evolve(z, 0.3, pkg.apply_H, m, kry_m=4).abs().max()) == 0.0
