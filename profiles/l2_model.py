@@ -83,8 +83,7 @@ def order_lex(tiles):
     return [tiles[x::8] for x in range(8)]
 
 
-def simulate(queue):
-    """events of one XCD -> (bytes requested, bytes missed)"""
+def events(queue):
     ev = []
     life = 1.0
     for j, P in enumerate(queue):
@@ -105,20 +104,55 @@ def simulate(queue):
         n = len(reads)
         for k, (obj, sz) in enumerate(reads):
             ev.append((t0 + life * (k // 2) / (n // 2 + 1), obj, sz))
+    return ev
+
+
+class LRU:
+    def __init__(self, cap):
+        self.cap, self.used, self.d = cap, 0, OrderedDict()
+
+    def access(self, obj, sz):
+        """True on a hit"""
+        if obj in self.d:
+            self.d.move_to_end(obj)
+            return True
+        self.d[obj] = sz
+        self.used += sz
+        while self.used > self.cap:
+            _, s2 = self.d.popitem(last=False)
+            self.used -= s2
+        return False
+
+
+def simulate(queue):
+    """events of one XCD -> (bytes requested, bytes missed)"""
+    ev = events(queue)
     ev.sort(key=lambda e: e[0])
-    lru, used, req, miss = OrderedDict(), 0, 0, 0
+    l2, req, miss = LRU(CAP), 0, 0
     for _, obj, sz in ev:
         req += sz
-        if obj in lru:
-            lru.move_to_end(obj)
-            continue
-        miss += sz
-        lru[obj] = sz
-        used += sz
-        while used > CAP:
-            _, s2 = lru.popitem(last=False)
-            used -= s2
+        if not l2.access(obj, sz):
+            miss += sz
     return req, miss
+
+
+def simulate_all(queues, mall_bytes):
+    """all eight XCDs with private L2s in front of one shared memory-side cache -> (requested, L2 misses, MALL misses)"""
+    ev = []
+    for x, q in enumerate(queues):
+        ev.extend((t, x, obj, sz) for (t, obj, sz) in events(q))
+    ev.sort(key=lambda e: e[0])
+    l2 = [LRU(CAP) for _ in queues]
+    mall = LRU(mall_bytes)
+    req = m2 = m3 = 0
+    for _, x, obj, sz in ev:
+        req += sz
+        if l2[x].access(obj, sz):
+            continue
+        m2 += sz
+        if not mall.access(obj, sz):
+            m3 += sz
+    return req, m2, m3
 
 
 def parse(name):
@@ -140,8 +174,14 @@ def parse(name):
 
 
 print(f"L={L} p={p} tiles in class: {len(all_tiles)}  rows: {sum(tile_len(P) for P in all_tiles)}")
+MALL = float(os.environ.get("MALL_MIB", "0"))          # > 0: simulate all XCDs behind a shared memory-side cache of this size
 for name in orders:
     q = parse(name)
+    if MALL > 0:
+        r, m2, m3 = simulate_all(q, int(MALL * (1 << 20)))
+        rows = sum(tile_len(P) for x in q for P in x)
+        print(f"{name:12s} read requests {r / rows:6.1f} B/row   L2 misses {m2 / rows:6.1f} B/row   memory-side misses {m3 / rows:6.1f} B/row", flush=True)
+        continue
     tot_req = tot_miss = 0
     for x in (0, 3):                       # two of the eight XCDs are enough for a rate
         r, m_ = simulate(q[x])
