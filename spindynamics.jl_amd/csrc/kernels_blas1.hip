@@ -41,6 +41,76 @@ __global__ __launch_bounds__(BS) void k_dot(const double *__restrict__ x, const 
   if (threadIdx.x == 0) { partials[2 * blockIdx.x] = a; partials[2 * blockIdx.x + 1] = b; }
 }
 
+// s[c] = sum_i V[c*ld + i] * y[i] for c = 0..nc-1 (real vectors, nc <= SD_MDOT_MAXC): the orthogonality checks of
+// lanczos_groundstate (src/Lanczos.jl:142-153 computes dot(V[:,k], w/beta) for every k) in one pass over y instead of one
+// pass per column.  Per-block partials [block][c], summed in block order by k_mdot_reduce (deterministic).
+constexpr int SD_MDOT_MAXC = 16;
+__global__ __launch_bounds__(BS) void k_mdot(const double *__restrict__ V, int64_t ld, int nc, const double *__restrict__ y,
+                                             int64_t N, double *__restrict__ partials) {
+  __shared__ double red[BS / 64][SD_MDOT_MAXC];
+  double acc[SD_MDOT_MAXC];
+#pragma unroll
+  for (int c = 0; c < SD_MDOT_MAXC; ++c) acc[c] = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += stride) {
+    const double yi = y[i];
+#pragma unroll
+    for (int c = 0; c < SD_MDOT_MAXC; ++c)
+      if (c < nc) acc[c] += V[(int64_t)c * ld + i] * yi;
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int c = 0; c < SD_MDOT_MAXC; ++c) {
+    double a = acc[c];
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, 64);
+    if (lane == 0) red[wv][c] = a;
+  }
+  __syncthreads();
+  if (threadIdx.x < SD_MDOT_MAXC) {
+    double a = 0.0;
+    for (int w = 0; w < BS / 64; ++w) a += red[w][threadIdx.x];
+    partials[(size_t)blockIdx.x * SD_MDOT_MAXC + threadIdx.x] = a;
+  }
+}
+__global__ __launch_bounds__(64 * SD_MDOT_MAXC) void k_mdot_reduce(const double *__restrict__ partials, int nb, int nc,
+                                                                   double *__restrict__ dst) {
+  const int c = threadIdx.x >> 6, lane = threadIdx.x & 63;     // one wave per column
+  double a = 0.0;
+  for (int b = lane; b < nb; b += 64) a += partials[(size_t)b * SD_MDOT_MAXC + c];
+  for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, 64);
+  if (lane == 0 && c < nc) dst[c] = a;
+}
+
+// One link of the modified Gram-Schmidt chain of lanczos_groundstate (src/Lanczos.jl:116-124) without a host round trip:
+//   if (v_sub) w -= (*s_dev) * v_sub;      then   partial sums of  v_dot . w   (reduced into a device scalar by k_reduce_to)
+// The next link reads that scalar on the device.  Same element order per thread as k_dot<1> / k_ew2 when the vectors are
+// 16-byte aligned; arithmetic w - s*v as in the un-fused pass.
+__global__ __launch_bounds__(BS) void k_sub_dot(double *__restrict__ w, const double *__restrict__ v_sub,
+                                                const double *__restrict__ s_dev, const double *__restrict__ v_dot, int64_t N,
+                                                double *__restrict__ partials) {
+  __shared__ double red[32];
+  const double sv = v_sub ? *s_dev : 0.0;
+  double a = 0.0, b = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const bool vec = !(((uintptr_t)w | (uintptr_t)v_dot | (uintptr_t)(v_sub ? v_sub : v_dot)) & 15);
+  const int64_t n2 = vec ? N / 2 : 0;
+  double2 *w2 = (double2 *)w;
+  const double2 *s2 = (const double2 *)v_sub, *d2 = (const double2 *)v_dot;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
+    double2 x = w2[i];
+    if (v_sub) { const double2 u = s2[i]; x.x = x.x - sv * u.x; x.y = x.y - sv * u.y; w2[i] = x; }
+    const double2 v = d2[i];
+    a += v.x * x.x + v.y * x.y;
+  }
+  for (int64_t i = 2 * n2 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += stride) {
+    double x = w[i];
+    if (v_sub) { x = x - sv * v_sub[i]; w[i] = x; }
+    a += v_dot[i] * x;
+  }
+  block_reduce2(a, b, red);
+  if (threadIdx.x == 0) { partials[2 * blockIdx.x] = a; partials[2 * blockIdx.x + 1] = b; }
+}
+
 __global__ __launch_bounds__(BS) void k_nrm2sq(const double *__restrict__ x, int64_t n, double *__restrict__ partials) {
   __shared__ double red[32];
   double a = 0.0, b = 0.0;
@@ -220,6 +290,40 @@ int sd_k_dot(sd_ctx *ctx, int nc, const double *x, const double *y, int64_t N, i
   else hipLaunchKernelGGL(k_dot<1>, dim3(nb), dim3(BS), 0, ctx->stream, x, y, N, ctx->d_partials);
   hipLaunchKernelGGL(k_reduce_to, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_partials, nb, ctx->d_scalars + slot);
   SD_HIP(ctx, hipGetLastError());
+  return SD_OK;
+}
+
+int sd_k_mgs_chain(sd_ctx *ctx, double *w, const double *V, int64_t ld, int ncols, int64_t N, int slot) {
+  // for k = 0..ncols-2: w -= dot(V[:,k], w) * V[:,k];  then dot(V[:,ncols-1], w) -> d_scalars[slot] (read it with sd_read_scalars).
+  // Every dot stays on the device (slot is re-used link after link); no host synchronisation inside the chain.
+  if (ncols <= 0) return SD_OK;
+  int rc = sd_ensure_partials(ctx, 2 * RED_BLOCKS); if (rc) return rc;
+  const int nb = (int)std::min<int64_t>(RED_BLOCKS, std::max<int64_t>(1, (N / 2 + BS - 1) / BS));
+  for (int k = 0; k < ncols; ++k) {
+    hipLaunchKernelGGL(k_sub_dot, dim3(nb), dim3(BS), 0, ctx->stream, w, k > 0 ? V + (int64_t)(k - 1) * ld : nullptr,
+                       ctx->d_scalars + slot, V + (int64_t)k * ld, N, ctx->d_partials);
+    hipLaunchKernelGGL(k_reduce_to, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_partials, nb, ctx->d_scalars + slot);
+  }
+  SD_HIP(ctx, hipGetLastError());
+  return SD_OK;
+}
+
+int sd_k_mdot(sd_ctx *ctx, const double *V, int64_t ld, int ncols, const double *y, int64_t N, double *out_host) {
+  // out_host[c] = V[:,c] . y for c < ncols (any ncols); one stream synchronisation at the end
+  if (ncols <= 0) return SD_OK;
+  const int groups = (ncols + SD_MDOT_MAXC - 1) / SD_MDOT_MAXC;
+  const int nb = (int)std::min<int64_t>(RED_BLOCKS, std::max<int64_t>(1, (N + BS - 1) / BS));
+  int rc = sd_ensure_partials(ctx, (size_t)nb * SD_MDOT_MAXC + (size_t)groups * SD_MDOT_MAXC); if (rc) return rc;
+  double *res = ctx->d_partials + (size_t)nb * SD_MDOT_MAXC;            // reduced dots of all groups
+  for (int g = 0; g < groups; ++g) {
+    const int c0 = g * SD_MDOT_MAXC, nc = std::min(SD_MDOT_MAXC, ncols - c0);
+    hipLaunchKernelGGL(k_mdot, dim3(nb), dim3(BS), 0, ctx->stream, V + (int64_t)c0 * ld, ld, nc, y, N, ctx->d_partials);
+    hipLaunchKernelGGL(k_mdot_reduce, dim3(1), dim3(64 * SD_MDOT_MAXC), 0, ctx->stream, ctx->d_partials, nb, nc,
+                       res + (size_t)g * SD_MDOT_MAXC);
+  }
+  SD_HIP(ctx, hipGetLastError());
+  SD_HIP(ctx, hipMemcpyAsync(out_host, res, sizeof(double) * (size_t)ncols, hipMemcpyDeviceToHost, ctx->stream));
+  SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return SD_OK;
 }
 

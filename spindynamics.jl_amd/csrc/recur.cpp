@@ -402,30 +402,32 @@ extern "C" int sd_lanczos_groundstate(sd_ctx *ctx, const sd_model *m, int lanc_m
     double *vj = V.p + N * (int64_t)(j - 1);
     RC(sd_launch_apply(ctx, m, SD_F64, w.p, vj, SD_EPI_PLAIN, ea));                       // :113
     double s[2];
-    for (int k = 1; k <= j - 1; ++k) {                                                   // :116-122
-      double *vk = V.p + N * (int64_t)(k - 1);
-      RC(sd_k_dot(ctx, 1, vk, w.p, N, 4)); RC(sd_read_scalars(ctx, 4, 1, s));
-      RC(sd_k_sub2(ctx, w.p, vk, nullptr, N, s[0], 0.0));
-    }
-    RC(sd_k_dot(ctx, 1, vj, w.p, N, 4)); RC(sd_read_scalars(ctx, 4, 1, s));
+    // :116-124: w -= dot(V[:,k], w) V[:,k] for k = 1..j-1, then alpha_j = dot(V[:,j], w) -- one chain of fused
+    // subtract-and-dot kernels whose scalars stay on the device; only alpha_j comes back to the host
+    RC(sd_k_mgs_chain(ctx, w.p, V.p, N, j, N, 4)); RC(sd_read_scalars(ctx, 4, 1, s));
     alpha[j - 1] = s[0];                                                                 // :124
     RC(sd_k_sub2(ctx, w.p, vj, j == 1 ? nullptr : V.p + N * (int64_t)(j - 2), N, alpha[j - 1],
                  j == 1 ? 0.0 : beta[j - 2]));                                           // :127-129
     if (j < mm) {
       beta[j - 1] = norm_dev(ctx, w.p, N, &rc); RC(rc);                                  // :133
       if (beta[j - 1] < tol) { m_actual = j; break; }                                    // :136-139
-      bool tmp_valid = false;
-      for (int k = 1; k <= j; ++k) {                                                     // :142-153
-        double *vk = V.p + N * (int64_t)(k - 1);
-        if (!tmp_valid) { RC(sd_k_scale_div(ctx, tmp.p, w.p, N, beta[j - 1])); tmp_valid = true; }
-        RC(sd_k_dot(ctx, 1, vk, tmp.p, N, 4)); RC(sd_read_scalars(ctx, 4, 1, s));
-        if (std::fabs(s[0]) > orth_tol) {
-          RC(sd_k_dot(ctx, 1, vk, w.p, N, 4)); RC(sd_read_scalars(ctx, 4, 1, s));
-          RC(sd_k_sub2(ctx, w.p, vk, nullptr, N, s[0], 0.0));
-          beta[j - 1] = norm_dev(ctx, w.p, N, &rc); RC(rc);
-          tmp_valid = false;
-          if (beta[j - 1] < tol) { m_actual = j; break; }                               // inner break only (:150)
-        }
+      // :142-153: for k = 1..j test |dot(V[:,k], w/beta)| > orth_tol and correct w when it fires (then w/beta changes).
+      // The tests between two corrections all use the same w/beta, so they are taken in one pass (sd_k_mdot) and the
+      // first one that fires is handled exactly as the reference's sequential loop would; the rest is tested again.
+      std::vector<double> chk(j);
+      for (int k = 1; k <= j;) {
+        RC(sd_k_scale_div(ctx, tmp.p, w.p, N, beta[j - 1]));
+        RC(sd_k_mdot(ctx, V.p + N * (int64_t)(k - 1), N, j - k + 1, tmp.p, N, chk.data()));
+        int hit = -1;
+        for (int q = 0; q < j - k + 1 && hit < 0; ++q)
+          if (std::fabs(chk[q]) > orth_tol) hit = k + q;
+        if (hit < 0) break;
+        double *vk = V.p + N * (int64_t)(hit - 1);
+        RC(sd_k_dot(ctx, 1, vk, w.p, N, 4)); RC(sd_read_scalars(ctx, 4, 1, s));
+        RC(sd_k_sub2(ctx, w.p, vk, nullptr, N, s[0], 0.0));
+        beta[j - 1] = norm_dev(ctx, w.p, N, &rc); RC(rc);
+        if (beta[j - 1] < tol) { m_actual = j; break; }                                 // inner break only (:150)
+        k = hit + 1;
       }
       RC(sd_k_scale_div(ctx, V.p + N * (int64_t)j, w.p, N, beta[j - 1]));                 // :155
     }
