@@ -133,6 +133,16 @@ __global__ __launch_bounds__(1024) void k_reduce_to(const double *__restrict__ p
 
 enum { OP_SCALE_DIV, OP_NEG, OP_SUB_AXPBY, OP_SUB_AXPBY1, OP_SUB2, OP_SUB2_1 };
 
+// scalars of an elementwise pass taken from DEVICE memory (results of earlier reductions of the same stream), so that a
+// recursion needs no host round trip between its passes: a = *a_dev (or sqrt(*a_dev)), b = *b_dev; the resolved a is stored
+// to *store_a by one thread (that is how alpha_j / beta_j of a Lanczos run are collected for one read-back at the end)
+struct EwDev { const double *a_dev = nullptr, *b_dev = nullptr; double *store_a = nullptr; int a_sqrt = 0; };
+__device__ __forceinline__ void ew_resolve(const EwDev &d, double &a, double &b) {
+  if (d.a_dev) a = d.a_sqrt ? sqrt(*d.a_dev) : *d.a_dev;
+  if (d.b_dev) b = *d.b_dev;
+  if (d.store_a && blockIdx.x == 0 && threadIdx.x == 0) *d.store_a = a;
+}
+
 template <int OP>
 __device__ __forceinline__ double ew_op(double w, double v, double u, double a, double b) {
   if (OP == OP_SCALE_DIV) return v / a;
@@ -148,8 +158,9 @@ template <int OP> struct ew_reads { static constexpr bool w = OP != OP_SCALE_DIV
 template <int OP, bool NORM>
 __global__ __launch_bounds__(BS) void k_ew2(double2 *__restrict__ w, const double2 *__restrict__ v,
                                             const double2 *__restrict__ u, int64_t n2, double a, double b,
-                                            double *__restrict__ partials) {
+                                            double *__restrict__ partials, EwDev dv) {
   __shared__ double red[32];
+  ew_resolve(dv, a, b);
   double s = 0.0, s1 = 0.0;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
@@ -169,8 +180,9 @@ __global__ __launch_bounds__(BS) void k_ew2(double2 *__restrict__ w, const doubl
 template <int OP, bool NORM>
 __global__ __launch_bounds__(BS) void k_ew(double *__restrict__ w, const double *__restrict__ v,
                                            const double *__restrict__ u, int64_t n, double a, double b,
-                                           double *__restrict__ partials) {
+                                           double *__restrict__ partials, EwDev dv) {
   __shared__ double red[32];
+  ew_resolve(dv, a, b);
   double s = 0.0, s1 = 0.0;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -347,19 +359,20 @@ int sd_read_scalars(sd_ctx *ctx, int slot, int count, double *out) {
 namespace {
 // one elementwise pass; when slot >= 0 the pass also reduces |w_new|^2 into ctx->d_scalars[slot]
 template <int OP>
-int launch_ew(sd_ctx *ctx, double *w, const double *v, const double *u, int64_t n, double a, double b, int slot) {
+int launch_ew(sd_ctx *ctx, double *w, const double *v, const double *u, int64_t n, double a, double b, int slot,
+              EwDev dv = EwDev()) {
   const bool vec = (n % 2 == 0) && !((((uintptr_t)w) | ((uintptr_t)v) | ((uintptr_t)u)) & 15);
   const int64_t items = vec ? n / 2 : n;
   unsigned nb = grid_for(items);
   if (slot >= 0) {
     if (nb > RED_BLOCKS) nb = RED_BLOCKS;
     int rc = sd_ensure_partials(ctx, 2 * RED_BLOCKS); if (rc) return rc;
-    if (vec) hipLaunchKernelGGL((k_ew2<OP, true>), dim3(nb), dim3(BS), 0, ctx->stream, (double2 *)w, (const double2 *)v, (const double2 *)u, items, a, b, ctx->d_partials);
-    else hipLaunchKernelGGL((k_ew<OP, true>), dim3(nb), dim3(BS), 0, ctx->stream, w, v, u, items, a, b, ctx->d_partials);
+    if (vec) hipLaunchKernelGGL((k_ew2<OP, true>), dim3(nb), dim3(BS), 0, ctx->stream, (double2 *)w, (const double2 *)v, (const double2 *)u, items, a, b, ctx->d_partials, dv);
+    else hipLaunchKernelGGL((k_ew<OP, true>), dim3(nb), dim3(BS), 0, ctx->stream, w, v, u, items, a, b, ctx->d_partials, dv);
     hipLaunchKernelGGL(k_reduce_to, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_partials, (int)nb, ctx->d_scalars + slot);
   } else {
-    if (vec) hipLaunchKernelGGL((k_ew2<OP, false>), dim3(nb), dim3(BS), 0, ctx->stream, (double2 *)w, (const double2 *)v, (const double2 *)u, items, a, b, (double *)nullptr);
-    else hipLaunchKernelGGL((k_ew<OP, false>), dim3(nb), dim3(BS), 0, ctx->stream, w, v, u, items, a, b, (double *)nullptr);
+    if (vec) hipLaunchKernelGGL((k_ew2<OP, false>), dim3(nb), dim3(BS), 0, ctx->stream, (double2 *)w, (const double2 *)v, (const double2 *)u, items, a, b, (double *)nullptr, dv);
+    else hipLaunchKernelGGL((k_ew<OP, false>), dim3(nb), dim3(BS), 0, ctx->stream, w, v, u, items, a, b, (double *)nullptr, dv);
   }
   SD_HIP(ctx, hipGetLastError());
   return SD_OK;
@@ -382,6 +395,17 @@ int sd_k_sub_axpby_nrm(sd_ctx *ctx, double *w, const double *v, const double *u,
 }
 int sd_k_sub2_nrm(sd_ctx *ctx, double *w, const double *v, const double *u, int64_t n, double a, double b, int slot) {
   return u ? launch_ew<OP_SUB2>(ctx, w, v, u, n, a, b, slot) : launch_ew<OP_SUB2_1>(ctx, w, v, nullptr, n, a, b, slot);
+}
+int sd_k_sub2_nrm_devs(sd_ctx *ctx, double *w, const double *v, const double *u, int64_t n, const double *a_dev,
+                       const double *b_dev, double *store_a, int slot) {
+  // w = (w - a v) - b u with a = *a_dev, b = *b_dev (device scalars; u / b_dev null: w - a v); |w|^2 -> d_scalars[slot]
+  EwDev dv; dv.a_dev = a_dev; dv.b_dev = u ? b_dev : nullptr; dv.store_a = store_a;
+  return u ? launch_ew<OP_SUB2>(ctx, w, v, u, n, 0.0, 0.0, slot, dv) : launch_ew<OP_SUB2_1>(ctx, w, v, nullptr, n, 0.0, 0.0, slot, dv);
+}
+int sd_k_scale_div_devs(sd_ctx *ctx, double *y, const double *x, int64_t n, const double *nrm2_dev, double *store_a) {
+  // y = x / sqrt(*nrm2_dev)  (correctly rounded sqrt, as std::sqrt on the host)
+  EwDev dv; dv.a_dev = nrm2_dev; dv.a_sqrt = 1; dv.store_a = store_a;
+  return launch_ew<OP_SCALE_DIV>(ctx, y, x, nullptr, n, 1.0, 0.0, -1, dv);
 }
 int sd_k_krylov_update_nrm(sd_ctx *ctx, double *w, const double *v, const double *u, int64_t N, double ar, double ai,
                            double b, int slot) {

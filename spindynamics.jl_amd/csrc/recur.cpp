@@ -171,31 +171,35 @@ int moments_dev(sd_ctx *ctx, const sd_model *m, const double *phi, int M, double
 
 int tridiag_dev(sd_ctx *ctx, const sd_model *m, double *vcur /* normalised start, consumed */, int lanc_m, double tol,
                 double *alpha, double *beta, int *m_eff_out) {
-  // lanczos_tridiag  src/Lanczos.jl:196-246 with two live vectors (the reference keeps all m)
+  // lanczos_tridiag  src/Lanczos.jl:196-246 with two live vectors (the reference keeps all m).
+  // No host round trip inside the loop: alpha_j and beta_j stay on the device (the update and normalisation passes read
+  // them there and file them into d_al / d_be), so the whole recursion is queued at once and read back once.  The
+  // reference's break on beta_j < tol (:228-231) is applied afterwards: the steps before it are unaffected by what was
+  // queued behind them, the rest is discarded.
   const int64_t n = m->N;
   const int mm = (int)std::min<int64_t>(lanc_m, n);
-  DBuf wb, vp;
-  RC(wb.alloc(ctx, 2 * n)); RC(vp.alloc(ctx, 2 * n));
-  double *w = wb.p, *vprev = vp.p;
-  for (int k = 0; k < mm; ++k) alpha[k] = 0.0;
-  for (int k = 0; k + 1 < mm; ++k) beta[k] = 0.0;
-  int m_eff = mm;
+  DBuf wb, vp, ab;
+  RC(wb.alloc(ctx, 2 * n)); RC(vp.alloc(ctx, 2 * n)); RC(ab.alloc(ctx, 2 * (int64_t)mm));
+  double *w = wb.p, *vprev = vp.p, *d_al = ab.p, *d_be = ab.p + mm;
+  SD_HIP(ctx, hipMemsetAsync(ab.p, 0, sizeof(double) * 2 * (size_t)mm, ctx->stream));
   sd_epi_args ea;
   for (int j = 1; j <= mm - 1; ++j) {
-    RC(sd_launch_apply(ctx, m, SD_C128, w, vcur, SD_EPI_DOT, ea));                                 // :218-219
-    double s[2]; RC(sd_read_scalars(ctx, 0, 2, s));
-    alpha[j - 1] = s[0];
-    RC(sd_k_sub2_nrm(ctx, w, vcur, j > 1 ? vprev : nullptr, 2 * n, alpha[j - 1], j > 1 ? beta[j - 2] : 0.0, 2));  // :222-224
-    { double q; RC(sd_read_scalars(ctx, 2, 1, &q)); beta[j - 1] = std::sqrt(q); }                   // :227 (fused)
-    if (beta[j - 1] < tol) { m_eff = j; break; }
+    RC(sd_launch_apply(ctx, m, SD_C128, w, vcur, SD_EPI_DOT, ea));                                 // :218-219 -> d_scalars[0]
+    RC(sd_k_sub2_nrm_devs(ctx, w, vcur, j > 1 ? vprev : nullptr, 2 * n, ctx->d_scalars + 0, j > 1 ? d_be + (j - 2) : nullptr,
+                          d_al + (j - 1), 2));                                                     // :222-224, |w|^2 -> [2]
     std::swap(vprev, vcur);
-    RC(sd_k_scale_div(ctx, vcur, w, 2 * n, beta[j - 1]));                                         // :233
+    RC(sd_k_scale_div_devs(ctx, vcur, w, 2 * n, ctx->d_scalars + 2, d_be + (j - 1)));              // :227, :233
   }
-  if (m_eff == mm) {                                                                              // :237-239
-    RC(sd_launch_apply(ctx, m, SD_C128, w, vcur, SD_EPI_DOT, ea));
-    double s[2]; RC(sd_read_scalars(ctx, 0, 2, s));
-    alpha[mm - 1] = s[0];
-  }
+  RC(sd_launch_apply(ctx, m, SD_C128, w, vcur, SD_EPI_DOT, ea));                                   // :237-239
+  SD_HIP(ctx, hipMemcpyAsync(d_al + (mm - 1), ctx->d_scalars + 0, sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  std::vector<double> host(2 * (size_t)mm);
+  SD_HIP(ctx, hipMemcpyAsync(host.data(), ab.p, sizeof(double) * 2 * (size_t)mm, hipMemcpyDeviceToHost, ctx->stream));
+  SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  int m_eff = mm;
+  for (int j = 1; j <= mm - 1; ++j)
+    if (!(host[mm + j - 1] >= tol)) { m_eff = j; break; }                                          // :228-231 (NaN counts as a break)
+  for (int k = 0; k < mm; ++k) alpha[k] = k < m_eff ? host[k] : 0.0;
+  for (int k = 0; k + 1 < mm; ++k) beta[k] = (m_eff < mm ? k < m_eff : k < mm - 1) ? host[mm + k] : 0.0;
   *m_eff_out = m_eff;
   return SD_OK;
 }

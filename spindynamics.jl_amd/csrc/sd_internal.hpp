@@ -191,6 +191,9 @@ int sd_launch_szq(sd_ctx *ctx, const sd_model *m, int dtype_in, const void *psi0
 // fixed, deterministic order; sd_read_scalars copies them to the host.
 int sd_k_dot(sd_ctx *ctx, int nc, const double *x, const double *y, int64_t N, int slot);  // conj(x).y -> [slot]=re,[slot+1]=im
 int sd_k_nrm2sq(sd_ctx *ctx, const double *x, int64_t n, int slot);
+int sd_k_sub2_nrm_devs(sd_ctx *ctx, double *w, const double *v, const double *u, int64_t n, const double *a_dev,
+                       const double *b_dev, double *store_a, int slot);   // scalars from device memory (no host round trip)
+int sd_k_scale_div_devs(sd_ctx *ctx, double *y, const double *x, int64_t n, const double *nrm2_dev, double *store_a);
 int sd_k_mgs_chain(sd_ctx *ctx, double *w, const double *V, int64_t ld, int ncols, int64_t N, int slot);   // MGS against V[:,0..ncols-2], then dot with V[:,ncols-1] -> d_scalars[slot]
 int sd_k_mdot(sd_ctx *ctx, const double *V, int64_t ld, int ncols, const double *y, int64_t N, double *out_host);   // out[c] = V[:,c].y (real)
 int sd_read_scalars(sd_ctx *ctx, int slot, int count, double *out);

@@ -310,3 +310,27 @@ def test_krylov_evolve_device_resident(pkg):
     assert b.dtype == torch.complex128 and np.array_equal(b.cpu().numpy(), a)
     z = torch.zeros(m.N, dtype=torch.complex128, device="cuda")          # zero state comes back unchanged (Krylov.jl:145-147)
     assert float(pkg.krylov_time_evolve(z, 0.3, pkg.apply_H, m, kry_m=4).abs().max()) == 0.0
+
+
+def test_lanczos_tridiag_breakdown_is_applied_after_the_queued_recursion(pkg, O, D):
+    """The device recursion queues every step without a host round trip and applies the reference's break on beta_j < tol
+    (src/Lanczos.jl:228-231) afterwards.  An exact eigenvector as start vector breaks down at the first step: alpha = [E],
+    beta = [] (or one tiny entry), nothing of the discarded steps (inf / NaN by then) leaks out."""
+    L, nup = 8, 4
+    m = pkg.XXZChain(L, nup=nup)
+    r = O.XXZChain(L, nup=nup)
+    v = np.ones(m.N, dtype=complex)                 # |F>: H|F> = (L-1)/4 |F> at the Heisenberg point
+    al, be, nv = pkg.lanczos_tridiag(pkg.apply_H, m, v, lanc_m=12)
+    assert len(al) == 1 and abs(al[0] - (L - 1) / 4) < 1e-14 and np.all(np.isfinite(al)) and np.all(np.isfinite(be))
+    assert abs(nv - np.sqrt(m.N)) < 1e-12
+    # breakdown in the middle: a start vector inside a 3-dimensional invariant subspace
+    hop, zz, f = D.xxz_lists(L)
+    w, U = np.linalg.eigh(D.dense_H(L, nup, hop, zz, f))
+    pick = [0, 5, 11]                                # three non-degenerate levels
+    assert min(abs(w[i] - w[j]) for i in pick for j in range(len(w)) if j != i) > 1e-6
+    v3 = (U[:, pick[0]] + 0.5 * U[:, pick[1]] - 0.25 * U[:, pick[2]]).astype(complex)
+    al, be, _ = pkg.lanczos_tridiag(pkg.apply_H, m, v3, lanc_m=12, tol=1e-9)
+    al_o, be_o, _ = O.lanczos_tridiag(r, v3, lanc_m=12, tol=1e-9)
+    assert len(al) == len(al_o) == 3 and np.all(np.isfinite(al)) and np.all(np.isfinite(be))
+    T = np.diag(al) + np.diag(be[:2], 1) + np.diag(be[:2], -1)
+    assert np.abs(np.linalg.eigvalsh(T) - np.sort(w[pick])).max() < 1e-9
