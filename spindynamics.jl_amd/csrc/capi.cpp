@@ -42,10 +42,17 @@ void sd_pool_give(sd_ctx *ctx, void *p, size_t bytes) {
     const char *e = getenv("SD_POOL_MAX_GB");
     return (size_t)((e ? atof(e) : 96.0) * 1e9);
   }();
+  if (bytes > cap) { (void)hipFree(p); return; }
+  // every block is kept (a hipMalloc/hipFree pair costs ~0.1 ms even for a few KB: hipFree waits for the device -- more than
+  // three Lanczos steps of a small system); the oldest blocks make room when the pool is full
+  ctx->pool_free.emplace_back(p, bytes);
   size_t held = 0;
   for (auto &b : ctx->pool_free) held += b.second;
-  if (bytes < ((size_t)64 << 20) || held + bytes > cap) { (void)hipFree(p); return; }   // small blocks are cheap to re-create
-  ctx->pool_free.emplace_back(p, bytes);
+  while (!ctx->pool_free.empty() && (held > cap || ctx->pool_free.size() > 256)) {
+    held -= ctx->pool_free.front().second;
+    (void)hipFree(ctx->pool_free.front().first);
+    ctx->pool_free.erase(ctx->pool_free.begin());
+  }
 }
 
 void sd_pool_release(sd_ctx *ctx) {

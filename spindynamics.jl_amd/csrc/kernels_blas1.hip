@@ -199,8 +199,15 @@ __global__ __launch_bounds__(BS) void k_ew(double *__restrict__ w, const double 
 // w = (w - alpha*v) - b*u  with complex alpha (src/TimeEvolution/Krylov.jl:156-159), fused |w|^2
 __global__ __launch_bounds__(BS) void k_krylov_update(double2 *__restrict__ w, const double2 *__restrict__ v,
                                                       const double2 *__restrict__ u, int64_t N, double ar, double ai,
-                                                      double b, int have_u, double *__restrict__ partials) {
+                                                      double b, int have_u, double *__restrict__ partials,
+                                                      const double *__restrict__ alpha_dev, const double *__restrict__ b_dev,
+                                                      double *__restrict__ store_alpha) {
   __shared__ double red[32];
+  if (alpha_dev) {            // alpha (re, im) and beta_prev from device memory: no host round trip between the passes
+    ar = alpha_dev[0]; ai = alpha_dev[1];
+    if (have_u) b = *b_dev;
+    if (store_alpha && blockIdx.x == 0 && threadIdx.x == 0) { store_alpha[0] = ar; store_alpha[1] = ai; }
+  }
   double s = 0.0, s1 = 0.0;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += stride) {
@@ -396,6 +403,12 @@ int sd_k_sub_axpby_nrm(sd_ctx *ctx, double *w, const double *v, const double *u,
 int sd_k_sub2_nrm(sd_ctx *ctx, double *w, const double *v, const double *u, int64_t n, double a, double b, int slot) {
   return u ? launch_ew<OP_SUB2>(ctx, w, v, u, n, a, b, slot) : launch_ew<OP_SUB2_1>(ctx, w, v, nullptr, n, a, b, slot);
 }
+int sd_k_sub_axpby_nrm_devs(sd_ctx *ctx, double *w, const double *v, const double *u, int64_t n, const double *a_dev,
+                            const double *b_dev, double *store_a, int slot) {
+  // w -= a v + b u with a = *a_dev, b = *b_dev (device scalars; u / b_dev null: w -= a v); |w|^2 -> d_scalars[slot]
+  EwDev dv; dv.a_dev = a_dev; dv.b_dev = u ? b_dev : nullptr; dv.store_a = store_a;
+  return u ? launch_ew<OP_SUB_AXPBY>(ctx, w, v, u, n, 0.0, 0.0, slot, dv) : launch_ew<OP_SUB_AXPBY1>(ctx, w, v, nullptr, n, 0.0, 0.0, slot, dv);
+}
 int sd_k_sub2_nrm_devs(sd_ctx *ctx, double *w, const double *v, const double *u, int64_t n, const double *a_dev,
                        const double *b_dev, double *store_a, int slot) {
   // w = (w - a v) - b u with a = *a_dev, b = *b_dev (device scalars; u / b_dev null: w - a v); |w|^2 -> d_scalars[slot]
@@ -413,7 +426,18 @@ int sd_k_krylov_update_nrm(sd_ctx *ctx, double *w, const double *v, const double
   unsigned nb = grid_for(N);
   if (nb > RED_BLOCKS) nb = RED_BLOCKS;
   hipLaunchKernelGGL(k_krylov_update, dim3(nb), dim3(BS), 0, ctx->stream, (double2 *)w, (const double2 *)v, (const double2 *)u, N,
-                     ar, ai, b, u ? 1 : 0, ctx->d_partials);
+                     ar, ai, b, u ? 1 : 0, ctx->d_partials, (const double *)nullptr, (const double *)nullptr, (double *)nullptr);
+  hipLaunchKernelGGL(k_reduce_to, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_partials, (int)nb, ctx->d_scalars + slot);
+  SD_HIP(ctx, hipGetLastError());
+  return SD_OK;
+}
+int sd_k_krylov_update_nrm_devs(sd_ctx *ctx, double *w, const double *v, const double *u, int64_t N, const double *alpha_dev,
+                                const double *b_dev, double *store_alpha, int slot) {
+  int rc = sd_ensure_partials(ctx, 2 * RED_BLOCKS); if (rc) return rc;
+  unsigned nb = grid_for(N);
+  if (nb > RED_BLOCKS) nb = RED_BLOCKS;
+  hipLaunchKernelGGL(k_krylov_update, dim3(nb), dim3(BS), 0, ctx->stream, (double2 *)w, (const double2 *)v, (const double2 *)u, N,
+                     0.0, 0.0, 0.0, u ? 1 : 0, ctx->d_partials, alpha_dev, b_dev, store_alpha);
   hipLaunchKernelGGL(k_reduce_to, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_partials, (int)nb, ctx->d_scalars + slot);
   SD_HIP(ctx, hipGetLastError());
   return SD_OK;

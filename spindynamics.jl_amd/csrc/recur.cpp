@@ -87,21 +87,28 @@ int extremal_dev(sd_ctx *ctx, const sd_model *m, int lanc_m, double tol, double 
   int rc = 0;
   double nrm = norm_dev(ctx, v_prev, 2 * N, &rc); RC(rc);
   RC(sd_k_scale_div(ctx, v_prev, v_prev, 2 * N, nrm));                     // :40
-  std::vector<double> alpha(mm, 0.0), beta(mm, 0.0);
-  int actual = mm;
+  // the loop is queued without host round trips (alpha_j, beta_j stay on the device, see tridiag_dev); the break on
+  // beta_j < tol (:66-70) is applied to the values read back at the end
+  DBuf ab; RC(ab.alloc(ctx, 2 * (int64_t)mm));
+  double *d_al = ab.p, *d_be = ab.p + mm;
+  SD_HIP(ctx, hipMemsetAsync(ab.p, 0, sizeof(double) * 2 * (size_t)mm, ctx->stream));
   sd_epi_args ea; ea.negate = negate;
   for (int j = 1; j <= mm; ++j) {
-    RC(sd_launch_apply(ctx, m, SD_C128, w.p, v_prev, SD_EPI_DOT, ea));     // :51 + :55 fused
-    double s[2]; RC(sd_read_scalars(ctx, 0, 2, s));
-    alpha[j - 1] = s[0];
-    RC(sd_k_sub_axpby_nrm(ctx, w.p, v_prev, j == 1 ? nullptr : v_curr, 2 * N, alpha[j - 1], j == 1 ? 0.0 : beta[j - 2], 2));
+    RC(sd_launch_apply(ctx, m, SD_C128, w.p, v_prev, SD_EPI_DOT, ea));     // :51 + :55 fused -> d_scalars[0]
+    RC(sd_k_sub_axpby_nrm_devs(ctx, w.p, v_prev, j == 1 ? nullptr : v_curr, 2 * N, ctx->d_scalars + 0,
+                               j == 1 ? nullptr : d_be + (j - 2), d_al + (j - 1), 2));
     if (j < mm) {
-      { double q; RC(sd_read_scalars(ctx, 2, 1, &q)); beta[j - 1] = std::sqrt(q); }   // :65 (norm fused into the update pass)
-      if (beta[j - 1] < tol) { actual = j; break; }                       // :66-70
       std::swap(v_curr, v_prev);
-      RC(sd_k_scale_div(ctx, v_prev, w.p, 2 * N, beta[j - 1]));           // :71
+      RC(sd_k_scale_div_devs(ctx, v_prev, w.p, 2 * N, ctx->d_scalars + 2, d_be + (j - 1)));   // :65, :71
     }
   }
+  std::vector<double> host(2 * (size_t)mm);
+  SD_HIP(ctx, hipMemcpyAsync(host.data(), ab.p, sizeof(double) * 2 * (size_t)mm, hipMemcpyDeviceToHost, ctx->stream));
+  SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  int actual = mm;
+  for (int j = 1; j < mm; ++j)
+    if (!(host[mm + j - 1] >= tol)) { actual = j; break; }                 // :66-70
+  std::vector<double> alpha(host.begin(), host.begin() + mm), beta(host.begin() + mm, host.end());
   std::vector<double> ev(actual);
   int rce = sd_symtridiag_eig(actual, alpha.data(), beta.data(), ev.data(), nullptr);   // :80-83
   if (rce) return sd_set_err(ctx, SD_EINTERNAL, "tridiagonal eigen-solver did not converge");
@@ -491,20 +498,31 @@ static int krylov_evolve_core(sd_ctx *ctx, const sd_model *m, int dtype, const v
   RC(sd_k_promote(ctx, V[0].p, inp, nc, n));
   if (norm0 == 0) return emit(V[0].p);                                                    // :145-147
   RC(sd_k_scale_div(ctx, V[0].p, V[0].p, 2 * n, norm0));                                  // :148
-  std::vector<double> alr(kry_m, 0.0), beta(kry_m, 0.0);
-  int m_eff = kry_m;
+  // the Lanczos part is queued without host round trips (see tridiag_dev): alpha_j (complex) and beta_j stay on the device
+  // and are read back once; the break on |beta_j| < 1e-14 (:162-168) is applied to the values afterwards
+  DBuf ab; RC(ab.alloc(ctx, 3 * (int64_t)kry_m));
+  double *d_al = ab.p, *d_be = ab.p + 2 * (int64_t)kry_m;          // alpha as (re, im) pairs, then beta
+  SD_HIP(ctx, hipMemsetAsync(ab.p, 0, sizeof(double) * 3 * (size_t)kry_m, ctx->stream));
   sd_epi_args ea;
   for (int j = 1; j <= kry_m; ++j) {
-    RC(sd_launch_apply(ctx, m, SD_C128, w.p, V[j - 1].p, SD_EPI_DOT, ea));                // :153,155
-    double s[2]; RC(sd_read_scalars(ctx, 0, 2, s));
-    alr[j - 1] = s[0];
-    RC(sd_k_krylov_update_nrm(ctx, w.p, V[j - 1].p, j > 1 ? V[j - 2].p : nullptr, n, s[0], s[1],
-                              j > 1 ? beta[j - 2] : 0.0, 2));                              // :156-159 + :161 in one pass
+    RC(sd_launch_apply(ctx, m, SD_C128, w.p, V[j - 1].p, SD_EPI_DOT, ea));                // :153,155 -> d_scalars[0..1]
+    RC(sd_k_krylov_update_nrm_devs(ctx, w.p, V[j - 1].p, j > 1 ? V[j - 2].p : nullptr, n, ctx->d_scalars + 0,
+                                   j > 1 ? d_be + (j - 2) : nullptr, d_al + 2 * (j - 1), 2));   // :156-159 + :161 in one pass
     if (j < kry_m) {
-      { double q; RC(sd_read_scalars(ctx, 2, 1, &q)); beta[j - 1] = std::sqrt(q); }
-      if (std::fabs(beta[j - 1]) < 1e-14) { m_eff = j; break; }                           // :162-168
       RC(V[j].alloc(ctx, 2 * n));
-      RC(sd_k_scale_div(ctx, V[j].p, w.p, 2 * n, beta[j - 1]));                           // :169
+      RC(sd_k_scale_div_devs(ctx, V[j].p, w.p, 2 * n, ctx->d_scalars + 2, d_be + (j - 1)));   // :161, :169
+    }
+  }
+  std::vector<double> hostab(3 * (size_t)kry_m);
+  SD_HIP(ctx, hipMemcpyAsync(hostab.data(), ab.p, sizeof(double) * 3 * (size_t)kry_m, hipMemcpyDeviceToHost, ctx->stream));
+  SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  std::vector<double> alr(kry_m, 0.0), beta(kry_m, 0.0);
+  int m_eff = kry_m;
+  for (int j = 1; j <= kry_m; ++j) {
+    alr[j - 1] = hostab[2 * (size_t)(j - 1)];
+    if (j < kry_m) {
+      beta[j - 1] = hostab[2 * (size_t)kry_m + (j - 1)];
+      if (!(std::fabs(beta[j - 1]) >= 1e-14)) { m_eff = j; break; }                       // :162-168
     }
   }
   // reduced problem on the host (:175-182).  Deviation (documented in DESIGN.md): Re(alpha) enters a

@@ -53,7 +53,7 @@ struct sd_ctx {
   double *h_scalars = nullptr;  // 16 doubles, pinned host
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // device work vectors of the recursion-level calls, kept between calls: hipMalloc of a 9.6 GB vector (L=32) takes
-  // 0.4-0.5 s, more than twenty applies.  sd_ctx_release_scratch / sd_ctx_destroy free them.
+  // 0.4-0.5 s, more than twenty applies, and a malloc/free pair of a few MB ~0.4 ms, more than ten small-system steps.  sd_ctx_release_scratch / sd_ctx_destroy free them.
   std::vector<std::pair<void *, size_t>> pool_free;
   void *stage[2] = {nullptr, nullptr};   // device staging of the host-pointer operator calls (sd_apply, ...), kept between calls
   size_t stage_cap[2] = {0, 0};
@@ -191,6 +191,10 @@ int sd_launch_szq(sd_ctx *ctx, const sd_model *m, int dtype_in, const void *psi0
 // fixed, deterministic order; sd_read_scalars copies them to the host.
 int sd_k_dot(sd_ctx *ctx, int nc, const double *x, const double *y, int64_t N, int slot);  // conj(x).y -> [slot]=re,[slot+1]=im
 int sd_k_nrm2sq(sd_ctx *ctx, const double *x, int64_t n, int slot);
+int sd_k_krylov_update_nrm_devs(sd_ctx *ctx, double *w, const double *v, const double *u, int64_t N, const double *alpha_dev,
+                                const double *b_dev, double *store_alpha, int slot);
+int sd_k_sub_axpby_nrm_devs(sd_ctx *ctx, double *w, const double *v, const double *u, int64_t n, const double *a_dev,
+                            const double *b_dev, double *store_a, int slot);
 int sd_k_sub2_nrm_devs(sd_ctx *ctx, double *w, const double *v, const double *u, int64_t n, const double *a_dev,
                        const double *b_dev, double *store_a, int slot);   // scalars from device memory (no host round trip)
 int sd_k_scale_div_devs(sd_ctx *ctx, double *y, const double *x, int64_t n, const double *nrm2_dev, double *store_a);
