@@ -78,7 +78,7 @@ if "kpm" in which:
         dt2 = time.time() - t0
         per_moment = (dt - dt2) / (M - M2) * 1e3
         per_apply = per_moment * (2 if doubling else 1)
-        print(json.dumps({"what": "KPM moments, %s (fused step incl. per-step scalar read-back)"
+        print(json.dumps({"what": "KPM moments, %s (fused step)"
                                   % ("2 per apply (default)" if doubling else "reference loop, 1 per apply"),
                           "L": L, "N": m.N, "ms_per_moment": per_moment, "ms_per_apply_step": per_apply,
                           "alg_B_per_row_step": bpr, "achieved_GBs": bpr * m.N / per_apply / 1e6,

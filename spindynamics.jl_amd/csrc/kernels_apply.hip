@@ -668,7 +668,8 @@ __global__ __launch_bounds__(256) void k_reduce_pairs_stage(const double *__rest
 }
 
 // partials[0 .. 2n) -> ctx->d_scalars[0..1]; the caller reserved 2n + 2*SD_RED_STAGE_BLOCKS doubles of ctx->d_partials
-int reduce_pairs(sd_ctx *ctx, int64_t n) {
+int reduce_pairs(sd_ctx *ctx, int64_t n, double *dst) {
+  if (!dst) dst = ctx->d_scalars;
   const double *src = ctx->d_partials;
   if (n > 16384) {
     double *stage = ctx->d_partials + 2 * n;
@@ -677,7 +678,7 @@ int reduce_pairs(sd_ctx *ctx, int64_t n) {
     SD_HIP(ctx, hipGetLastError());
     src = stage; n = SD_RED_STAGE_BLOCKS;
   }
-  hipLaunchKernelGGL(k_reduce_pairs, dim3(1), dim3(1024), 0, ctx->stream, src, n, ctx->d_scalars);
+  hipLaunchKernelGGL(k_reduce_pairs, dim3(1), dim3(1024), 0, ctx->stream, src, n, dst);
   SD_HIP(ctx, hipGetLastError());
   return SD_OK;
 }
@@ -782,7 +783,7 @@ int sd_launch_apply(sd_ctx *ctx, const sd_model *m, int dtype, void *out, const 
       if (rc) return rc;
     }
     if (sums) {
-      int rc2 = reduce_pairs(ctx, (int64_t)(nt + ng));
+      int rc2 = reduce_pairs(ctx, (int64_t)(nt + ng), ea.sums_dst);
       if (rc2) return rc2;
     }
   } else if (m->full_ls > 0) {
@@ -797,7 +798,7 @@ int sd_launch_apply(sd_ctx *ctx, const sd_model *m, int dtype, void *out, const 
                        ctx->d_partials);
     SD_HIP(ctx, hipGetLastError());
     if (sums) {
-      int rc2 = reduce_pairs(ctx, (int64_t)nb);
+      int rc2 = reduce_pairs(ctx, (int64_t)nb, ea.sums_dst);
       if (rc2) return rc2;
     }
   } else {
@@ -812,7 +813,7 @@ int sd_launch_apply(sd_ctx *ctx, const sd_model *m, int dtype, void *out, const 
                          (const double *)psi, epi, ea, ctx->d_partials);
     SD_HIP(ctx, hipGetLastError());
     if (sums) {
-      int rc2 = reduce_pairs(ctx, (int64_t)nb);
+      int rc2 = reduce_pairs(ctx, (int64_t)nb, ea.sums_dst);
       if (rc2) return rc2;
     }
   }

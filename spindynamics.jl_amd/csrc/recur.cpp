@@ -157,19 +157,26 @@ int moments_dev(sd_ctx *ctx, const sd_model *m, const double *phi, int M, double
     // If the reference's overflow guard (:118-121, |v| > 1e3: the bounds do not contain the spectrum) would fire, the
     // identity no longer mirrors what the reference computes, so the reference recursion is run instead.
     ea.phi = nullptr;                                           // epilogue: s0 = Re<v_curr|v_next>, s1 = |v_next|^2
+    // every step is queued without a host round trip: step n files its two sums at d_sum[2n..2n+1]; one read-back at the end
+    const int nsteps = M / 2;                                   // applies: v_1 .. v_nsteps
+    DBuf sm; RC(sm.alloc(ctx, 2 * (int64_t)nsteps + 2));
+    ea.sums_dst = sm.p;
     RC(sd_launch_apply(ctx, m, SD_C128, v_curr, v_prev, SD_EPI_RESCALE_DOT, ea));
-    RC(sd_read_scalars(ctx, 0, 2, s));
-    mu[1] = s[0];
-    if (M > 2) mu[2] = 2.0 * s[1] - mu[0];
-    bool guard = false;
-    for (int n = 1; 2 * n + 1 <= M - 1 && !guard; ++n) {
-      ea.prev = v_prev;
+    for (int n = 1; n < nsteps; ++n) {
+      ea.prev = v_prev; ea.sums_dst = sm.p + 2 * n;
       RC(sd_launch_apply(ctx, m, SD_C128, v_next, v_curr, SD_EPI_KPM, ea));                         // v_{n+1}
-      RC(sd_read_scalars(ctx, 0, 2, s));
-      mu[2 * n + 1] = 2.0 * s[0] - mu[1];
-      if (2 * n + 2 <= M - 1) mu[2 * n + 2] = 2.0 * s[1] - mu[0];
-      if (std::sqrt(s[1]) > 1e3) guard = true;
       double *t = v_prev; v_prev = v_curr; v_curr = v_next; v_next = t;
+    }
+    std::vector<double> hs(2 * (size_t)nsteps);
+    SD_HIP(ctx, hipMemcpyAsync(hs.data(), sm.p, sizeof(double) * 2 * (size_t)nsteps, hipMemcpyDeviceToHost, ctx->stream));
+    SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    bool guard = false;
+    for (int k = 1; k <= nsteps; ++k) {                         // sums of step k: [Re<v_{k-1}|v_k>, |v_k|^2]
+      const double s0 = hs[2 * (size_t)(k - 1)], s1 = hs[2 * (size_t)(k - 1) + 1];
+      if (k == 1) mu[1] = s0;
+      else if (2 * k - 1 <= M - 1) mu[2 * k - 1] = 2.0 * s0 - mu[1];
+      if (2 * k <= M - 1) mu[2 * k] = 2.0 * s1 - mu[0];
+      if (!(std::sqrt(s1) <= 1e3)) guard = true;
     }
     if (!guard) return SD_OK;
   }

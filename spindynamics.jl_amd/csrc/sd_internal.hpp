@@ -174,6 +174,7 @@ struct sd_epi_args {
   void *accv = nullptr;         // psi_t (CHEB)
   const void *phi = nullptr;    // KPM reference vector
   int negate = 0;               // PLAIN / DOT: out = -(H psi)
+  double *sums_dst = nullptr;   // where the two reduced sums of a DOT / KPM / RESCALE_DOT epilogue go (device; null: ctx->d_scalars[0..1])
   const void *halo = nullptr;   // sharded plans: imported partner tiles (offsets >= n_local); null = halo follows psi's owned rows
 };
 // Launches the apply with the chosen epilogue.  When the epilogue produces
