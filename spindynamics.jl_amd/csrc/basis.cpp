@@ -354,7 +354,12 @@ int sd_build_plan(sd_model *m, int rank, int nranks, std::string &err) {
     m->n_local += tlen[k];
     m->max_tile_len = std::max<int>(m->max_tile_len, (int)tlen[k]);
   }
-  if (m->row_lo < 0) m->row_lo = 0;
+  if (m->row_lo < 0) {
+    // a rank without tiles (more ranks than tiles or cells): an empty range placed where the next owner's rows begin
+    m->row_lo = m->row_hi = m->N;
+    for (size_t k = 0; k < T; ++k)
+      if (owner[k] > rank) { m->row_lo = m->row_hi = tiles[k].base; break; }
+  }
 
   std::vector<int64_t> xcd_scratch((size_t)1 << p, -1);
   xcd_order(m, p, m->tile_prefix, m->tile_base, xcd_scratch);

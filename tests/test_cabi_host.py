@@ -148,9 +148,26 @@ def imported_rows(models, slabs, r):
 @pytest.mark.parametrize("L,nup,P", [(12, 6, 2), (14, 7, 3), (16, 8, 2), (16, 8, 8), (18, 9, 4), (17, 5, 5)])
 def test_shard_plan_is_consistent(pkg, L, nup, P, mode, monkeypatch):
     monkeypatch.setenv("SD_SUFFIX_BITS", "6")      # many tiles even at small L
+    check_shard_plan(pkg, L, nup, P, mode, "open")
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SD_PLAN_FUZZ_N", "30"))))
+def test_shard_plan_random(pkg, seed, monkeypatch):
+    """Seeded random sector, rank count (also more ranks than cells), tile size, ownership mode and boundary condition: the
+    owned rows partition the basis, sends pair with receives, and every hop partner of every owned row -- the periodic bond
+    included -- is owned or imported.  The multi-GPU path cannot be run on hardware here; this is its plan-level proof."""
+    rng = np.random.default_rng(900 + seed)
+    L = int(rng.integers(8, 19))
+    nup = int(rng.integers(1, L))
+    P = int(rng.integers(2, 9))
+    monkeypatch.setenv("SD_SUFFIX_BITS", str(int(rng.integers(3, 11))))
+    check_shard_plan(pkg, L, nup, P, str(rng.choice(["range", "class"])), str(rng.choice(["open", "periodic"])))
+
+
+def check_shard_plan(pkg, L, nup, P, mode, boundary):
     models = []
     for r in range(P):
-        m = pkg.XXZChain(L, nup=nup, ctx=None)
+        m = pkg.XXZChain(L, nup=nup, ctx=None, boundary=boundary)
         m.set_shard(r, P, mode)
         models.append(m)
     infos = [m.shard_info() for m in models]
@@ -158,8 +175,7 @@ def test_shard_plan_is_consistent(pkg, L, nup, P, mode, monkeypatch):
     # the owned rows of all ranks partition [0, N)
     rows = [m.local_rows() for m in models]
     assert np.array_equal(np.sort(np.concatenate(rows)), np.arange(N))
-    if mode == "range":
-        assert all(int(i.mode) == 0 for i in infos)
+    if all(int(i.mode) == 0 for i in infos):        # (class mode falls back to ranges for plans with few prefix sites)
         assert infos[0].row_lo == 0 and infos[-1].row_hi == N
         for a, b in zip(infos[:-1], infos[1:]):
             assert a.row_hi == b.row_lo
@@ -181,8 +197,9 @@ def test_shard_plan_is_consistent(pkg, L, nup, P, mode, monkeypatch):
             assert sum(c for (_, _, c, _g) in send) == infos[r].n_send
             assert all(len([1 for (peer, _, _, _g) in send if peer == q]) <= 1 for q in range(P))
     # every hop partner of every owned row is either owned or inside the halo
-    full = pkg.XXZChain(L, nup=nup, ctx=None)
+    full = pkg.XXZChain(L, nup=nup, ctx=None, boundary=boundary)
     st = full.states
+    bonds = [(i, i + 1) for i in range(1, L)] + ([(L, 1)] if boundary == "periodic" and L > 2 else [])
     for r in range(P):
         have = np.zeros(N, dtype=bool)
         have[rows[r]] = True
@@ -190,10 +207,10 @@ def test_shard_plan_is_consistent(pkg, L, nup, P, mode, monkeypatch):
         assert (imp >= 0).all()
         have[imp] = True
         mine = st[rows[r]].astype(np.uint64)
-        for i in range(1, L):
+        for (i, j) in bonds:
             bi = (mine >> np.uint64(i - 1)) & np.uint64(1)
-            bj = (mine >> np.uint64(i)) & np.uint64(1)
-            fl = mine[bi != bj] ^ np.uint64((1 << (i - 1)) | (1 << i))
+            bj = (mine >> np.uint64(j - 1)) & np.uint64(1)
+            fl = mine[bi != bj] ^ np.uint64((1 << (i - 1)) | (1 << (j - 1)))
             assert have[full.rank(fl)].all()
 
 
