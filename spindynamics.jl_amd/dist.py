@@ -288,11 +288,64 @@ class ShardedOperator:
                 v_prev, v_curr, v_next = v_curr, v_next, v_prev
         return mu
 
-    def kpm_sqw(self, psi0, q_list, omega, a, b, kpm_m=200, kernel="jackson", group=None):
-        """kpm_sqw (src/KPM_Sqw.jl:191-256) with explicit (a, b) on a sharded ComplexF64/Float64 psi0."""
+    # ---- Lanczos on a sharded state (energy bounds for the sharded KPM / Chebyshev drivers) ----
+    def lanczos_extremal(self, lanc_m=100, tol=1e-12, psi0=None, seed=0, group=None, device="cuda", negate=False):
+        """lanczos_extremal (src/Lanczos.jl:27-84) with the vectors sharded: returns (Emin, Emax) of the Lanczos matrix.
+        psi0: this rank's owned part of the start vector (ComplexF64); default: the counter-based N(0,1) vector of `seed`
+        (identical for every sharding).  One halo exchange + one fused apply per step; alpha, beta are all-reduced."""
         import numpy as np
         import torch
-        from .solvers import get_kernel, kpm_reconstruct
+        from .solvers import symtridiag_eig
+        N = self.model.N
+        mm = int(min(int(lanc_m), N))
+        if mm < 1:
+            raise _lib.ArgumentError("lanc_m must be >= 1")
+        if psi0 is None:
+            v_prev = self.fill_randn(self.empty(torch.complex128, device), seed)
+        else:
+            v_prev = psi0.to(torch.complex128).clone()
+        nrm = self.norm(v_prev, group)
+        if nrm == 0:
+            raise _lib.ZeroNormError("starting vector has zero norm")
+        v_prev /= nrm                                                       # :40
+        v_curr = torch.zeros_like(v_prev)
+        w = torch.empty_like(v_prev)
+        alpha, beta = np.zeros(mm), np.zeros(mm)
+        actual = mm
+        for j in range(1, mm + 1):
+            self.apply(w, v_prev, group)                                    # :51
+            if negate:                                                      # apply_H_neg! of estimate_energy_bounds (:260-264)
+                w.neg_()
+            alpha[j - 1] = self.dot(v_prev, w, group).real                  # :55
+            if j == 1:
+                w -= alpha[j - 1] * v_prev                                  # :59
+            else:
+                w -= alpha[j - 1] * v_prev + beta[j - 2] * v_curr
+            if j < mm:
+                beta[j - 1] = self.norm(w, group)                           # :65
+                if beta[j - 1] < tol:                                       # :66-70
+                    actual = j
+                    break
+                v_curr, v_prev = v_prev, v_curr
+                torch.div(w, beta[j - 1], out=v_prev)                       # :71
+        ev = symtridiag_eig(alpha[:actual], beta[:max(actual - 1, 0)], vectors=False)
+        return float(ev[0]), float(ev[-1])
+
+    def estimate_energy_bounds(self, lanc_m=80, seed=0, group=None, device="cuda"):
+        """estimate_energy_bounds (src/Lanczos.jl:255-271): Emax from a Lanczos run on H, Emin = -Emax of a run on -H."""
+        _, Emax = self.lanczos_extremal(lanc_m, seed=2 * seed + 1, group=group, device=device)
+        _, Emax_neg = self.lanczos_extremal(lanc_m, seed=2 * seed + 2, group=group, device=device, negate=True)
+        return -Emax_neg, Emax
+
+    def kpm_sqw(self, psi0, q_list, omega, a=None, b=None, kpm_m=200, kernel="jackson", group=None, seed=0):
+        """kpm_sqw (src/KPM_Sqw.jl:191-256) on a sharded ComplexF64/Float64 psi0; without (a, b) the rescaling is estimated as
+        the reference does (:212-214: energy bounds from two Lanczos runs, lanc_m = 80)."""
+        import numpy as np
+        import torch
+        from .solvers import get_kernel, kpm_reconstruct, rescaling_from_bounds
+        if a is None or b is None:
+            Emin, Emax = self.estimate_energy_bounds(80, seed, group, psi0.device)
+            a, b = rescaling_from_bounds(Emin, Emax)
         psic = psi0.to(torch.complex128)
         tmp = torch.empty_like(psic)
         self.apply(tmp, psic, group)

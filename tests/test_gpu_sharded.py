@@ -164,3 +164,33 @@ def test_kpm_q_replicas_two_processes_one_gpu():
                        cwd=root, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert r.stdout.count("replicas == single: True") == 2
+
+
+def test_sharded_lanczos_bounds_and_kpm_without_explicit_rescaling(pkg, O, monkeypatch):
+    """Sharded lanczos_extremal / estimate_energy_bounds (driver logic with one rank) against the C-ABI recursion on the same
+    generated start vector, and kpm_sqw estimating (a, b) itself as the reference does (src/KPM_Sqw.jl:212-214)."""
+    import torch
+    monkeypatch.setenv("SD_SUFFIX_BITS", "8")
+    L, nup = 14, 7
+    m = pkg.XXZChain(L, nup=nup, Jz=0.8)
+    r = O.XXZChain(L, nup=nup, Jz=0.8)
+    op = pkg.ShardedOperator(m, 0, 1)
+    start = op.fill_randn(op.empty(torch.complex128, "cuda"), 5)
+    lo, hi = op.lanczos_extremal(lanc_m=60, psi0=start)
+    lo2, hi2 = pkg.lanczos_extremal(pkg.apply_H, m, lanc_m=60, psi0=start.cpu().numpy())
+    assert abs(lo - lo2) < 1e-10 and abs(hi - hi2) < 1e-10            # converged extremal Ritz values
+    nlo, nhi = op.lanczos_extremal(lanc_m=60, psi0=start, negate=True)
+    assert abs(nhi + lo) < 1e-9 and abs(nlo + hi) < 1e-9               # spectrum of -H
+    Emin, Emax = op.estimate_energy_bounds(lanc_m=60)
+    w = np.linalg.eigvalsh(np.asarray([O.apply_H(r, e) for e in np.eye(m.N)]).T.real) if m.N <= 4000 else None
+    if w is not None:
+        assert abs(Emin - w[0]) < 1e-8 and abs(Emax - w[-1]) < 1e-6
+    with pytest.raises(pkg.ZeroNormError):
+        op.lanczos_extremal(lanc_m=5, psi0=torch.zeros(m.N, dtype=torch.complex128, device="cuda"))
+    psi0 = np.random.default_rng(8).standard_normal(m.N)
+    psi0 /= np.linalg.norm(psi0)
+    q, omega = pkg.momenta(m)[:2], np.arange(-2.0, 4.0, 0.2)
+    S = op.kpm_sqw(torch.from_numpy(psi0).cuda(), q, omega, kpm_m=64)
+    a, b = pkg.rescaling_from_bounds(Emin, Emax) if hasattr(pkg, "rescaling_from_bounds") else O.rescaling_from_bounds(Emin, Emax)
+    S2 = O.kpm_sqw(r, psi0, q, omega, a, b, kpm_m=64)
+    assert np.isfinite(S).all() and np.abs(S - S2).max() <= 1e-6 * max(1.0, np.abs(S2).max())   # bounds agree to 1e-8, not to the bit
