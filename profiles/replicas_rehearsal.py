@@ -23,7 +23,8 @@ a, b = L / 2 + 1.0, 0.0
 S = pkg.kpm_sqw_replicas(psi0, m, q, omega, a, b, kpm_m=64)
 ref = pkg.kpm_sqw(psi0, m, q, omega, a=a, b=b, kpm_m=64)
 ok = np.array_equal(S, ref)
-print("rank", dist.get_rank(), "of", dist.get_world_size(), "replicas == single:", ok, flush=True)
+sys.stdout.write("rank %d of %d replicas == single: %s\n" % (dist.get_rank(), dist.get_world_size(), bool(ok)))   # one write: no interleaving
+sys.stdout.flush()
 dist.barrier()
 dist.destroy_process_group()
 sys.exit(0 if ok else 1)

@@ -1,0 +1,65 @@
+"""End-to-end rehearsal of the sharded drivers with several REAL processes sharing one GPU (gloo; the halo messages are
+staged through the host, see dist.py): every rank owns a shard of the state, and its owned rows of
+  apply, chebyshev_time_evolve, kpm_moments (two per apply and the reference loop), lanczos_extremal, S(q,w)
+must equal what the unsharded single-GPU path gives.  Launch:
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node 3 --master-addr 127.0.0.1 --master-port 29544 profiles/sharded_rehearsal.py"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import torch.distributed as dist
+import __graft_entry__ as g
+
+os.environ["LOCAL_RANK"] = "0"          # all ranks share the one GPU of the box
+os.environ.setdefault("SD_SUFFIX_BITS", "8")
+pkg = g.load_package()
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+L, nup = 16, 8
+ok = True
+for mode in ("class", "range"):
+    full = pkg.XXZChain(L, nup=nup, Jz=0.7)
+    m = pkg.XXZChain(L, nup=nup, Jz=0.7)
+    op = pkg.ShardedOperator(m, rank, world, mode=mode)
+    rows = m.local_rows()
+    rng = np.random.default_rng(11)                       # same state on every rank
+    psi = rng.standard_normal(full.N) + 1j * rng.standard_normal(full.N)
+    psi /= np.linalg.norm(psi)
+    mine = torch.from_numpy(psi[rows].copy()).cuda()
+    # apply
+    want = np.empty_like(psi)
+    pkg.apply_H(want, psi, full)
+    out = torch.empty_like(mine)
+    op.apply(out, mine)
+    ok &= bool(np.array_equal(out.cpu().numpy(), want[rows]))
+    # Chebyshev evolution (even and odd numbers of terms)
+    for cn in (9, 12):
+        ref = pkg.chebyshev_time_evolve(psi, 0.3, pkg.apply_H, full, cheb_n=cn, Ebounds=(-8.5, 5.0))
+        got = op.chebyshev_time_evolve(mine, 0.3, cheb_n=cn, Ebounds=(-8.5, 5.0)).cpu().numpy()
+        ok &= bool(np.abs(got - ref[rows]).max() <= 1e-15)
+    # KPM moments
+    a, b = L / 2 + 1.0, 0.0
+    mu_ref = pkg.compute_chebyshev_moments(pkg.apply_H, psi, 21, a, b, full)
+    for dbl in (True, False):
+        mu = op.kpm_moments(mine, 21, a, b, doubling=dbl)
+        ok &= bool(np.abs(mu - mu_ref).max() <= 1e-13)
+    # Lanczos bounds on the same generated start vector
+    start = op.fill_randn(op.empty(torch.complex128, "cuda"), 5)
+    lo, hi = op.lanczos_extremal(lanc_m=50, psi0=start)
+    s_full = np.empty(full.N, dtype=complex)
+    pkg.check(pkg.lib().sd_fill_randn_host(s_full.view(np.float64).ctypes.data_as(__import__("ctypes").POINTER(__import__("ctypes").c_double)),
+                                           2 * full.N, 5, 0))
+    lo2, hi2 = pkg.lanczos_extremal(pkg.apply_H, full, lanc_m=50, psi0=s_full)
+    ok &= abs(lo - lo2) < 1e-10 and abs(hi - hi2) < 1e-10
+    # S(q, w)
+    q, omega = pkg.momenta(full)[:3], np.arange(-1.0, 4.0, 0.25)
+    S = op.kpm_sqw(mine, q, omega, a=a, b=b, kpm_m=40)
+    S_ref = pkg.kpm_sqw(psi, full, q, omega, a=a, b=b, kpm_m=40)
+    ok &= bool(np.abs(S - S_ref).max() <= 1e-10 * max(1.0, np.abs(S_ref).max()))
+    sys.stdout.write("rank %d of %d mode %s n_local %d n_halo %d sharded == single: %s\n" % (rank, world, mode, op.n_local, op.n_halo, bool(ok)))
+    sys.stdout.flush()
+dist.barrier()
+dist.destroy_process_group()
+sys.exit(0 if ok else 1)

@@ -194,3 +194,23 @@ def test_sharded_lanczos_bounds_and_kpm_without_explicit_rescaling(pkg, O, monke
     a, b = pkg.rescaling_from_bounds(Emin, Emax) if hasattr(pkg, "rescaling_from_bounds") else O.rescaling_from_bounds(Emin, Emax)
     S2 = O.kpm_sqw(r, psi0, q, omega, a, b, kpm_m=64)
     assert np.isfinite(S).all() and np.abs(S - S2).max() <= 1e-6 * max(1.0, np.abs(S2).max())   # bounds agree to 1e-8, not to the bit
+
+
+def test_sharded_drivers_three_processes_one_gpu():
+    """Every sharded driver (apply with the overlapped exchange, Chebyshev pairs, KPM moments both ways, Lanczos bounds,
+    S(q,w)) with three real processes sharing this GPU, in both ownership modes; gloo carries the halo messages through the
+    host (dist.py stages them), which exercises the same request / wait / part-1 / part-2 sequence as RCCL does."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(root, "profiles", "sharded_rehearsal.py")],
+                       cwd=root, capture_output=True, text=True, timeout=400)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.stdout.count("sharded == single: True") == 6
