@@ -53,6 +53,12 @@ const _ctx = Ref{Union{Nothing,Context}}(nothing)
 default_context() = (_ctx[] === nothing && (_ctx[] = Context()); _ctx[])
 
 # ---- Model: same descriptor fields as SpinModel.Model minus states/idxmap ----------
+# Context options (include/spindyn.h): Chebyshev moments two per apply (default) or the reference's one-per-apply loop;
+# release of the device vectors a context keeps between calls (staging of sd_apply, pooled work vectors of the recursions).
+set_kpm_doubling!(ctx::Context, on::Bool) =
+    check(ccall((:sd_ctx_set_kpm_doubling, libspindyn), Cint, (Ptr{Cvoid}, Cint), ctx.h, on ? 1 : 0), ctx.h)
+release_scratch!(ctx::Context) = check(ccall((:sd_ctx_release_scratch, libspindyn), Cint, (Ptr{Cvoid},), ctx.h), ctx.h)
+
 mutable struct Model
     L::Int
     nup::Union{Nothing,Int}
