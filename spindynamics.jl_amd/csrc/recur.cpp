@@ -75,6 +75,20 @@ double norm_dev(sd_ctx *ctx, const double *x, int64_t n, int *rc) {
   return std::sqrt(v);
 }
 
+// Every SD_BREAK_PEEK steps the queued recursions read back the betas filed so far (one small copy + one synchronisation)
+// and stop queueing when one is below tol or not a number: the reference's break (src/Lanczos.jl:66-70, 228-231) is then
+// at most SD_BREAK_PEEK - 1 discarded steps late instead of lanc_m - j.
+constexpr int SD_BREAK_PEEK = 32;
+int peek_breakdown(sd_ctx *ctx, const double *d_be, int count, double tol, std::vector<double> &buf, bool *broke) {
+  buf.resize((size_t)count);
+  SD_HIP(ctx, hipMemcpyAsync(buf.data(), d_be, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, ctx->stream));
+  SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  *broke = false;
+  for (int k = 0; k < count; ++k)
+    if (!(std::fabs(buf[k]) >= tol)) { *broke = true; break; }
+  return SD_OK;
+}
+
 // lanczos_extremal on device vectors; d_start (2N doubles, un-normalised) is consumed
 int extremal_dev(sd_ctx *ctx, const sd_model *m, int lanc_m, double tol, double *v_prev, int negate,
                  double *emin, double *emax) {
@@ -93,6 +107,7 @@ int extremal_dev(sd_ctx *ctx, const sd_model *m, int lanc_m, double tol, double 
   double *d_al = ab.p, *d_be = ab.p + mm;
   SD_HIP(ctx, hipMemsetAsync(ab.p, 0, sizeof(double) * 2 * (size_t)mm, ctx->stream));
   sd_epi_args ea; ea.negate = negate;
+  std::vector<double> peek;
   for (int j = 1; j <= mm; ++j) {
     RC(sd_launch_apply(ctx, m, SD_C128, w.p, v_prev, SD_EPI_DOT, ea));     // :51 + :55 fused -> d_scalars[0]
     RC(sd_k_sub_axpby_nrm_devs(ctx, w.p, v_prev, j == 1 ? nullptr : v_curr, 2 * N, ctx->d_scalars + 0,
@@ -100,6 +115,11 @@ int extremal_dev(sd_ctx *ctx, const sd_model *m, int lanc_m, double tol, double 
     if (j < mm) {
       std::swap(v_curr, v_prev);
       RC(sd_k_scale_div_devs(ctx, v_prev, w.p, 2 * N, ctx->d_scalars + 2, d_be + (j - 1)));   // :65, :71
+    }
+    if (j % SD_BREAK_PEEK == 0 && j < mm) {
+      bool broke = false;
+      RC(peek_breakdown(ctx, d_be, j, tol, peek, &broke));
+      if (broke) break;
     }
   }
   std::vector<double> host(2 * (size_t)mm);
@@ -197,12 +217,18 @@ int tridiag_dev(sd_ctx *ctx, const sd_model *m, double *vcur /* normalised start
   double *w = wb.p, *vprev = vp.p, *d_al = ab.p, *d_be = ab.p + mm;
   SD_HIP(ctx, hipMemsetAsync(ab.p, 0, sizeof(double) * 2 * (size_t)mm, ctx->stream));
   sd_epi_args ea;
+  std::vector<double> peek;
   for (int j = 1; j <= mm - 1; ++j) {
     RC(sd_launch_apply(ctx, m, SD_C128, w, vcur, SD_EPI_DOT, ea));                                 // :218-219 -> d_scalars[0]
     RC(sd_k_sub2_nrm_devs(ctx, w, vcur, j > 1 ? vprev : nullptr, 2 * n, ctx->d_scalars + 0, j > 1 ? d_be + (j - 2) : nullptr,
                           d_al + (j - 1), 2));                                                     // :222-224, |w|^2 -> [2]
     std::swap(vprev, vcur);
     RC(sd_k_scale_div_devs(ctx, vcur, w, 2 * n, ctx->d_scalars + 2, d_be + (j - 1)));              // :227, :233
+    if (j % SD_BREAK_PEEK == 0 && j < mm - 1) {       // bound the work queued behind a breakdown: look at the betas so far
+      bool broke = false;
+      RC(peek_breakdown(ctx, d_be, j, tol, peek, &broke));
+      if (broke) break;
+    }
   }
   RC(sd_launch_apply(ctx, m, SD_C128, w, vcur, SD_EPI_DOT, ea));                                   // :237-239
   SD_HIP(ctx, hipMemcpyAsync(d_al + (mm - 1), ctx->d_scalars + 0, sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
