@@ -21,7 +21,7 @@ def test_virtual_shards_bit_identical(pkg, L, nup, P, ls, mode, monkeypatch):
     check_virtual_shards(pkg, L, nup, P, mode, {})
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("SD_SHARD_FUZZ_N", "24"))))
 def test_virtual_shards_random(pkg, seed, monkeypatch):
     """Seeded random sector, rank count, tile size, ownership mode, boundary condition and couplings."""
     rng = np.random.default_rng(500 + seed)
