@@ -110,3 +110,34 @@ def test_config5_shard_of_L36_exact(pkg, rank):
     halo.fill_(1.0)
     op._launch(out, psi, halo, 0, part=2)
     assert bool((out == (L - 1) / 4).all())
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_bench_plans_of_L32_every_rank_exact(pkg, world):
+    """The plans `bench.py --gpus 2|4|8` runs (L=32, popcount-cell ownership): every rank's shard, one after the other on
+    this GPU, with the halo filled locally (uniform state) -- H|F> = (L-1)/4 |F> bit for bit on every owned row, in one
+    launch and as interior + boundary launches."""
+    import torch
+    L = 32
+    total = 0
+    for rank in range(world):
+        model = pkg.XXZChain(L, nup=L // 2)
+        op = pkg.ShardedOperator(model, rank, world, exchange_fn=lambda o, p, h: h.fill_(1.0))
+        psi = op.empty(torch.complex128, "cuda")
+        out = op.empty(torch.complex128, "cuda")
+        psi.fill_(1.0)
+        out.zero_()
+        op.apply(out, psi)
+        assert bool((out == (L - 1) / 4).all()), (world, rank)
+        halo = op.halo(psi)
+        halo.fill_(float("nan"))
+        out.zero_()
+        op._launch(out, psi, halo, 0, part=1)                  # interior tiles never touch the halo
+        assert not bool(torch.isnan(out.real).any())
+        halo.fill_(1.0)
+        op._launch(out, psi, halo, 0, part=2)
+        assert bool((out == (L - 1) / 4).all()), (world, rank, "parts")
+        total += op.n_local
+        del psi, out, halo, op, model
+        torch.cuda.empty_cache()
+    assert total == 601080390
