@@ -112,9 +112,10 @@ def test_config5_shard_of_L36_exact(pkg, rank):
     assert bool((out == (L - 1) / 4).all())
 
 
+@pytest.mark.parametrize("mode", ["class", "range"])
 @pytest.mark.parametrize("world", [2, 4, 8])
-def test_bench_plans_of_L32_every_rank_exact(pkg, world):
-    """The plans `bench.py --gpus 2|4|8` runs (L=32, popcount-cell ownership): every rank's shard, one after the other on
+def test_bench_plans_of_L32_every_rank_exact(pkg, world, mode):
+    """The plans `bench.py --gpus 2|4|8` runs (L=32, popcount-cell ownership; index ranges are its fall-back): every rank's shard, one after the other on
     this GPU, with the halo filled locally (uniform state) -- H|F> = (L-1)/4 |F> bit for bit on every owned row, in one
     launch and as interior + boundary launches."""
     import torch
@@ -122,7 +123,7 @@ def test_bench_plans_of_L32_every_rank_exact(pkg, world):
     total = 0
     for rank in range(world):
         model = pkg.XXZChain(L, nup=L // 2)
-        op = pkg.ShardedOperator(model, rank, world, exchange_fn=lambda o, p, h: h.fill_(1.0))
+        op = pkg.ShardedOperator(model, rank, world, exchange_fn=lambda o, p, h: h.fill_(1.0), mode=mode)
         psi = op.empty(torch.complex128, "cuda")
         out = op.empty(torch.complex128, "cuda")
         psi.fill_(1.0)
