@@ -223,21 +223,8 @@ __global__ __launch_bounds__(BS) void k_krylov_update(double2 *__restrict__ w, c
   if (threadIdx.x == 0) { partials[2 * blockIdx.x] = s; partials[2 * blockIdx.x + 1] = 0.0; }
 }
 
-// w -= alpha*v (complex alpha) ; y += alpha*x
-template <int SIGN>
-__global__ __launch_bounds__(BS) void k_caxpy(double2 *__restrict__ w, const double2 *__restrict__ v, int64_t N,
-                                              double ar, double ai) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += stride) {
-    double2 x = v[i], y = w[i];
-    const double tr = ar * x.x - ai * x.y, ti = ar * x.y + ai * x.x;
-    if (SIGN < 0) { y.x -= tr; y.y -= ti; } else { y.x += tr; y.y += ti; }
-    w[i] = y;
-  }
-}
-
 // y (+)= sum_k (cr[k] + i ci[k]) * X_k, columns given by pointer, accumulated in column order with exactly the arithmetic
-// of one k_caxpy<1> pass per column (psi_t .+= y[k] * V[k], src/TimeEvolution/Krylov.jl:186-188): same bits, one read of
+// of one complex axpy pass per column, y += (cr + i ci) x evaluated component-wise (psi_t .+= y[k] * V[k], src/TimeEvolution/Krylov.jl:186-188): same bits, one read of
 // every column and one write of y instead of a read-modify-write of y per column.
 constexpr int SD_CCOMB_MAXC = 16;
 struct CCombArgs { const double2 *x[SD_CCOMB_MAXC]; double cr[SD_CCOMB_MAXC], ci[SD_CCOMB_MAXC]; };
@@ -389,20 +376,10 @@ int launch_ew(sd_ctx *ctx, double *w, const double *v, const double *u, int64_t 
 int sd_k_scale_div(sd_ctx *ctx, double *y, const double *x, int64_t n, double d) {
   return launch_ew<OP_SCALE_DIV>(ctx, y, x, nullptr, n, d, 0.0, -1);
 }
-int sd_k_neg(sd_ctx *ctx, double *x, int64_t n) { return launch_ew<OP_NEG>(ctx, x, nullptr, nullptr, n, 0.0, 0.0, -1); }
-int sd_k_sub_axpby(sd_ctx *ctx, double *w, const double *v, const double *u, int64_t n, double a, double b) {
-  return u ? launch_ew<OP_SUB_AXPBY>(ctx, w, v, u, n, a, b, -1) : launch_ew<OP_SUB_AXPBY1>(ctx, w, v, nullptr, n, a, b, -1);
-}
 int sd_k_sub2(sd_ctx *ctx, double *w, const double *v, const double *u, int64_t n, double a, double b) {
   return u ? launch_ew<OP_SUB2>(ctx, w, v, u, n, a, b, -1) : launch_ew<OP_SUB2_1>(ctx, w, v, nullptr, n, a, b, -1);
 }
 // fused forms: same update + |w|^2 -> d_scalars[slot]
-int sd_k_sub_axpby_nrm(sd_ctx *ctx, double *w, const double *v, const double *u, int64_t n, double a, double b, int slot) {
-  return u ? launch_ew<OP_SUB_AXPBY>(ctx, w, v, u, n, a, b, slot) : launch_ew<OP_SUB_AXPBY1>(ctx, w, v, nullptr, n, a, b, slot);
-}
-int sd_k_sub2_nrm(sd_ctx *ctx, double *w, const double *v, const double *u, int64_t n, double a, double b, int slot) {
-  return u ? launch_ew<OP_SUB2>(ctx, w, v, u, n, a, b, slot) : launch_ew<OP_SUB2_1>(ctx, w, v, nullptr, n, a, b, slot);
-}
 int sd_k_sub_axpby_nrm_devs(sd_ctx *ctx, double *w, const double *v, const double *u, int64_t n, const double *a_dev,
                             const double *b_dev, double *store_a, int slot) {
   // w -= a v + b u with a = *a_dev, b = *b_dev (device scalars; u / b_dev null: w -= a v); |w|^2 -> d_scalars[slot]
@@ -420,17 +397,6 @@ int sd_k_scale_div_devs(sd_ctx *ctx, double *y, const double *x, int64_t n, cons
   EwDev dv; dv.a_dev = nrm2_dev; dv.a_sqrt = 1; dv.store_a = store_a;
   return launch_ew<OP_SCALE_DIV>(ctx, y, x, nullptr, n, 1.0, 0.0, -1, dv);
 }
-int sd_k_krylov_update_nrm(sd_ctx *ctx, double *w, const double *v, const double *u, int64_t N, double ar, double ai,
-                           double b, int slot) {
-  int rc = sd_ensure_partials(ctx, 2 * RED_BLOCKS); if (rc) return rc;
-  unsigned nb = grid_for(N);
-  if (nb > RED_BLOCKS) nb = RED_BLOCKS;
-  hipLaunchKernelGGL(k_krylov_update, dim3(nb), dim3(BS), 0, ctx->stream, (double2 *)w, (const double2 *)v, (const double2 *)u, N,
-                     ar, ai, b, u ? 1 : 0, ctx->d_partials, (const double *)nullptr, (const double *)nullptr, (double *)nullptr);
-  hipLaunchKernelGGL(k_reduce_to, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_partials, (int)nb, ctx->d_scalars + slot);
-  SD_HIP(ctx, hipGetLastError());
-  return SD_OK;
-}
 int sd_k_krylov_update_nrm_devs(sd_ctx *ctx, double *w, const double *v, const double *u, int64_t N, const double *alpha_dev,
                                 const double *b_dev, double *store_alpha, int slot) {
   int rc = sd_ensure_partials(ctx, 2 * RED_BLOCKS); if (rc) return rc;
@@ -439,16 +405,6 @@ int sd_k_krylov_update_nrm_devs(sd_ctx *ctx, double *w, const double *v, const d
   hipLaunchKernelGGL(k_krylov_update, dim3(nb), dim3(BS), 0, ctx->stream, (double2 *)w, (const double2 *)v, (const double2 *)u, N,
                      0.0, 0.0, 0.0, u ? 1 : 0, ctx->d_partials, alpha_dev, b_dev, store_alpha);
   hipLaunchKernelGGL(k_reduce_to, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_partials, (int)nb, ctx->d_scalars + slot);
-  SD_HIP(ctx, hipGetLastError());
-  return SD_OK;
-}
-int sd_k_csub(sd_ctx *ctx, double *w, const double *v, int64_t N, double ar, double ai) {
-  hipLaunchKernelGGL(k_caxpy<-1>, dim3(grid_for(N)), dim3(BS), 0, ctx->stream, (double2 *)w, (const double2 *)v, N, ar, ai);
-  SD_HIP(ctx, hipGetLastError());
-  return SD_OK;
-}
-int sd_k_cacc(sd_ctx *ctx, double *y, const double *x, int64_t N, double ar, double ai) {
-  hipLaunchKernelGGL(k_caxpy<1>, dim3(grid_for(N)), dim3(BS), 0, ctx->stream, (double2 *)y, (const double2 *)x, N, ar, ai);
   SD_HIP(ctx, hipGetLastError());
   return SD_OK;
 }

@@ -203,21 +203,14 @@ int sd_k_mgs_chain(sd_ctx *ctx, double *w, const double *V, int64_t ld, int ncol
 int sd_k_mdot(sd_ctx *ctx, const double *V, int64_t ld, int ncols, const double *y, int64_t N, double *out_host);   // out[c] = V[:,c].y (real)
 int sd_read_scalars(sd_ctx *ctx, int slot, int count, double *out);
 int sd_k_scale_div(sd_ctx *ctx, double *y, const double *x, int64_t n, double d);      // y = x / d
-int sd_k_neg(sd_ctx *ctx, double *x, int64_t n);
 // w = w - (a*v + b*u)   (lanczos_extremal form, src/Lanczos.jl:59-61); u may be null (b ignored)
-int sd_k_sub_axpby(sd_ctx *ctx, double *w, const double *v, const double *u, int64_t n, double a, double b);
 // w = (w - a*v) - b*u   (two roundings: src/Lanczos.jl:222-224, :127-129); u may be null
 int sd_k_sub2(sd_ctx *ctx, double *w, const double *v, const double *u, int64_t n, double a, double b);
 // fused update + squared norm into d_scalars[slot] (one pass instead of update, norm)
-int sd_k_sub_axpby_nrm(sd_ctx *ctx, double *w, const double *v, const double *u, int64_t n, double a, double b, int slot);
-int sd_k_sub2_nrm(sd_ctx *ctx, double *w, const double *v, const double *u, int64_t n, double a, double b, int slot);
-int sd_k_krylov_update_nrm(sd_ctx *ctx, double *w, const double *v, const double *u, int64_t N, double ar, double ai, double b, int slot);
 // w -= (ar + i ai) * v  for complex vectors (src/TimeEvolution/Krylov.jl:156)
-int sd_k_csub(sd_ctx *ctx, double *w, const double *v, int64_t N, double ar, double ai);
 // y += (ar + i ai) * x  complex accumulate (Krylov reconstruction :186-188)
 int sd_k_ccombine(sd_ctx *ctx, double *y, const double *const *cols, int64_t N, int ncols, const double *cr,
                   const double *ci);   // y = sum_k (cr+i ci)[k] * cols[k], column order, bit-identical to ncols k_cacc passes on y = 0
-int sd_k_cacc(sd_ctx *ctx, double *y, const double *x, int64_t N, double ar, double ai);
 // y = c0*x0 (+ c1*x1) complex  (Chebyshev start, src/TimeEvolution/Chebyshev.jl:96-102)
 int sd_k_cheb_init(sd_ctx *ctx, double *y, const double *x0, const double *x1, int64_t N, double c0r, double c0i,
                    double c1r, double c1i, int have1);
