@@ -65,3 +65,20 @@ if 4 in which:
         out = pkg.time_evolve(m, out, 0.5, method="chebyshev", cheb_n=100, Ebounds=(-14.5, 8.5))
         more.append(time.time() - t0)
     print(json.dumps({"config": 4, "what": "... two further steps of the same evolution (work vectors reused)", "seconds": more}), flush=True)
+
+if 5 in which:      # not a BASELINE config: the PublicAPI defaults at scale (Lanczos ground state, Lanczos S(q,w))
+    L = 28
+    m = pkg.XXZChain(L, nup=L // 2)
+    t0 = time.time()
+    E0, gs = pkg.groundstate(m, lanc_m=100)
+    dt = time.time() - t0
+    print(json.dumps({"config": "5a", "what": "groundstate(:lanczos, lanc_m=100), L=28 (full re-orthogonalisation)", "N": m.N,
+                      "seconds": dt, "E0_per_site": E0 / L}), flush=True)
+    q = pkg.momenta(m)[: L // 2 + 1]
+    omega = np.arange(0.0, 5.0 + 1e-9, 0.05)
+    t0 = time.time()
+    S = pkg.dynamical_structure_factor(m, gs, q, omega, method="lanczos", lanc_m=200, eta=0.05)
+    dt = time.time() - t0
+    print(json.dumps({"config": "5b", "what": "dynamical_structure_factor(:lanczos, lanc_m=200), L=28 ground state, %d momenta" % len(q),
+                      "N": m.N, "seconds": dt, "seconds_per_q": dt / len(q), "S_finite": bool(np.isfinite(S).all()),
+                      "S_max": float(S.max())}), flush=True)
