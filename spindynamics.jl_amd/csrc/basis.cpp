@@ -480,7 +480,7 @@ int sd_build_plan(sd_model *m, int rank, int nranks, std::string &err) {
         boundary[k] = bd;
       }
     }
-    bool split = ns >= 4096;
+    bool split = ns >= 32768;   // measured: three launches lose at L=24 (4 096 tiles, +38 %) and L=26 (16 384, +6 %), win from L=28 (65 536, -10 %)
     if (const char *e = getenv("SD_LEN_CLASSES")) split = atoi(e) >= 2 || (split && atoi(e) != 0);   // 2: also for small plans
     int top = 0;                                     // class of the longest tile: the only class when not splitting
     while (top < SD_N_LEN_CLASS - 1 && (64 << top) * 4 < m->max_tile_len) ++top;

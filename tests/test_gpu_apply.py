@@ -114,7 +114,7 @@ def test_dimension_and_argument_errors(pkg):
 
 @pytest.mark.parametrize("ls", ["11", "12", "13"])
 def test_tile_length_classes_bit_exact(pkg, O, ls, monkeypatch):
-    """Plans with >= 4096 tiles launch one kernel per tile length class (64/128/256-thread workgroups).  SD_LEN_CLASSES=2
+    """Plans with >= 32768 tiles launch one kernel per tile length class (64/128/256-thread workgroups).  SD_LEN_CLASSES=2
     forces the split on plans small enough for the oracle: plain, rescaled and the reduction epilogues (KPM moments)."""
     monkeypatch.setenv("SD_LEN_CLASSES", "2")
     monkeypatch.setenv("SD_SUFFIX_BITS", ls)
