@@ -3,15 +3,22 @@
 // separate rescale pass of apply_rescaled_H! (:286-301, fused here into the
 // store), and Sz_q_vector (:307-337).
 //
-// Two device paths:
+// Device paths:
 //  * k_apply_tiled   -- fixed-nup sector.  One workgroup per TILE (all rows
 //    sharing a prefix configuration of sites 1..p, see sd_internal.hpp).  The
 //    tile's psi is staged once in LDS; hops on bonds inside the suffix are LDS
 //    reads at idx +- C(LS-a-1,u) (no search, no hash); hops on prefix bonds
 //    are coalesced streams from another whole tile at the same in-tile offset;
 //    the straddling bond is a coalesced stream from half a tile.
-//  * k_apply_generic -- any model (full 2^L basis, L up to 63, arbitrary
-//    bonds): one row per thread, combinadic unrank / rank per hop.
+//  * k_apply_fulltile -- full 2^L basis, L >= 12: idx = state, 2^10 consecutive
+//    rows are a tile; chain bonds inside are LDS reads at i ^ (3 << (a-1)),
+//    higher bonds whole-tile streams from T ^ (3 << b).
+//  * k_apply_grouped  -- experimental (SD_GROUP_BONDS): 4/8 related tiles per workgroup.
+//  * k_apply_generic -- any other model (L up to 63, arbitrary bonds, huge
+//    prefix spaces): one row per thread, combinadic unrank / rank per hop.
+// sd_launch_apply picks the path and, for tiled plans with many tiles, issues one
+// launch per tile length class (64 / 128 / 256 / 512 / 1024 threads) and per part
+// (interior / boundary tiles of a sharded plan).
 //
 // Per-row operation order follows the reference exactly (fields, zz in list
 // order, value = diag*psi[idx], then hops in list order, value += J*psi[idx'])
@@ -40,11 +47,15 @@ namespace {
 //   2. every wave builds, in its own registers (lane b-1 <-> prefix bond b, lane
 //      p-1 <-> the straddling bond), the list of flippable far bonds with the
 //      partner tile's base offset -- no LDS, no barrier, one memory latency;
-//   3. the far-bond partner rows are streamed with a two-deep ping-pong
+//   3. the first far-bond stream is requested; own rows and the binomial table
+//      go to LDS and the only barrier follows at once (all waves are at the same
+//      point; afterwards each wave runs on its own clock);
+//   4. the far-bond partner rows are streamed with a two-deep ping-pong
 //      pipeline (loads of bond k+1 in flight while bond k is accumulated);
-//   4. own rows go to LDS, barrier, then the suffix bonds are LDS reads at
-//      idx +- C(LS-a-1,u);
-//   5. fused epilogue + store.
+//   5. the gathers of the first general bond (e.g. the periodic (L,1) bond) are
+//      requested into the idle stream registers; the suffix bonds are LDS reads at
+//      idx +- C(LS-a-1,u); then the general bonds;
+//   6. fused epilogue + store.
 // Accumulation order per row is the reference's bond order 1..L-1.  When every
 // NN hop amplitude is a power of two (XXZChain default 0.5) J*psi is exact and
 // acc + J*psi is evaluated with one fma (bit-identical to the unfused form).
