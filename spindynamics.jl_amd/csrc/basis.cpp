@@ -564,14 +564,21 @@ int sd_upload_model(sd_model *m, std::string &err) {
       double q = (m->zz_J[0] * 0.5) * 0.5;
       if (exact_multiples(q, (int)m->zz_J.size())) { d.diag_mode = 1; d.diag_q = q; }
     }
-    if (d.diag_mode == 1 && m->L >= 2 && (int)m->zz_i.size() >= m->L - 1) {
-      bool nn = true;
-      for (int k = 0; k < m->L - 1; ++k)
-        if (m->zz_i[k] != k + 1 || m->zz_j[k] != k + 2) nn = false;
-      if (nn) d.n_zz_nn = m->L - 1;
-    }
+  }
+  if (m->L >= 2 && (int)m->zz_i.size() >= m->L - 1) {     // leading zz bonds = the chain in order: anti-parallel bits in one xor
+    bool nn = true;
+    for (int k = 0; k < m->L - 1; ++k)
+      if (m->zz_i[k] != k + 1 || m->zz_j[k] != k + 2) nn = false;
+    if (nn) d.n_zz_nn = m->L - 1;
   }
   if (getenv("SD_EXACT_DIAG")) d.diag_mode = 0;
+  if (getenv("SD_DIAG_LITERAL")) d.diag_mode = 2;
+  // list-order diagonal: (J * (+-0.5)) * (+-0.5) = +-(J/4) and h * (+-0.5) = +-(h/2) exactly (binary scaling), so each term
+  // of the reference's sequential sum is a sign applied to a constant: same bits, a select and an add per term
+  m->zz_q.resize(m->zz_J.size());
+  for (size_t k = 0; k < m->zz_J.size(); ++k) m->zz_q[k] = (m->zz_J[k] * 0.5) * 0.5;
+  m->field_h.resize(m->field.size());
+  for (size_t k = 0; k < m->field.size(); ++k) m->field_h[k] = m->field[k] * 0.5;
   m->hop_pow2 = true;
   for (int k = 0; k < d.nn_hops; ++k) {
     int ex; const double mant = std::frexp(m->hop_J[k], &ex);
@@ -587,6 +594,8 @@ int sd_upload_model(sd_model *m, std::string &err) {
   if ((rc = up(m, m->zz_j, &d.zz_j, err))) return rc;
   if ((rc = up(m, m->zz_J, &d.zz_J, err))) return rc;
   if ((rc = up(m, m->field, &d.field, err))) return rc;
+  if ((rc = up(m, m->zz_q, &d.zz_q, err))) return rc;
+  if ((rc = up(m, m->field_h, &d.field_h, err))) return rc;
   if ((rc = up(m, m->binom, &d.binom, err))) return rc;
   d.n_tiles = (int)m->tile_prefix.size();
   if (m->p >= 0) {

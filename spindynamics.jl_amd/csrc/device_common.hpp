@@ -36,9 +36,51 @@ __device__ __forceinline__ double diag_of(const sd_dev_model &dm, uint64_t s) {
     return dm.diag_q * (double)(dm.n_zz - 2 * anti);
   }
   double d = 0.0;
-  for (int i = 1; i <= dm.L; ++i) d += dm.field[i - 1] * sz_of((s >> (i - 1)) & 1);
-  for (int k = 0; k < dm.n_zz; ++k)
-    d += (dm.zz_J[k] * sz_of((s >> (dm.zz_i[k] - 1)) & 1)) * sz_of((s >> (dm.zz_j[k] - 1)) & 1);
+  if (dm.diag_mode == 2) {   // the reference's loop, literally (SD_DIAG_LITERAL; what diag_mode 0 is checked against)
+    for (int i = 1; i <= dm.L; ++i) d += dm.field[i - 1] * sz_of((s >> (i - 1)) & 1);
+    for (int k = 0; k < dm.n_zz; ++k)
+      d += (dm.zz_J[k] * sz_of((s >> (dm.zz_i[k] - 1)) & 1)) * sz_of((s >> (dm.zz_j[k] - 1)) & 1);
+    return d;
+  }
+  // Same sum, same order, same bits: every term is +-(h_i/2) or +-(J_k/4) exactly, so it is selected, not multiplied.
+  // All-zero fields add +-0 to 0 and are skipped.
+  if (!dm.field_zero)
+    for (int i = 0; i < dm.L; ++i) { const double h = dm.field_h[i]; d += ((s >> i) & 1) ? h : -h; }
+  const uint64_t x = s ^ (s >> 1);                               // bit k: sites k+1, k+2 anti-parallel
+  for (int k = 0; k < dm.n_zz_nn; ++k) { const double q = dm.zz_q[k]; d += ((x >> k) & 1) ? -q : q; }
+  for (int k = dm.n_zz_nn; k < dm.n_zz; ++k) {
+    const double q = dm.zz_q[k];
+    d += (((s >> (dm.zz_i[k] - 1)) ^ (s >> (dm.zz_j[k] - 1))) & 1) ? -q : q;
+  }
+  return d;
+}
+
+// The list-order diagonal (diag_mode 0) split for a tile: the leading terms of the reference's sum depend on the prefix
+// configuration P only -- the field terms of sites 1..p, or (all fields zero) the zz terms of the chain bonds inside the
+// prefix -- so a thread forms them once (diag_head) and continues the same sequential sum per row (diag_tail).  Same
+// order, same bits as diag_of.
+struct DiagHead { double d0; int zz_from; };
+__device__ __forceinline__ DiagHead diag_head(const sd_dev_model &dm, uint32_t P, int p) {
+  DiagHead h{0.0, 0};
+  if (!dm.field_zero) {
+    for (int i = 0; i < p; ++i) { const double f = dm.field_h[i]; h.d0 += ((P >> i) & 1u) ? f : -f; }
+  } else if (dm.n_zz_nn > 0 && p >= 2) {
+    const uint32_t x = P ^ (P >> 1);
+    for (int k = 0; k < p - 1; ++k) { const double q = dm.zz_q[k]; h.d0 += ((x >> k) & 1u) ? -q : q; }
+    h.zz_from = p - 1;
+  }
+  return h;
+}
+__device__ __forceinline__ double diag_tail(const sd_dev_model &dm, const DiagHead &h, uint64_t s, int p) {
+  double d = h.d0;
+  if (!dm.field_zero)
+    for (int i = p; i < dm.L; ++i) { const double f = dm.field_h[i]; d += ((s >> i) & 1) ? f : -f; }
+  const uint64_t x = s ^ (s >> 1);
+  for (int k = h.zz_from; k < dm.n_zz_nn; ++k) { const double q = dm.zz_q[k]; d += ((x >> k) & 1) ? -q : q; }
+  for (int k = dm.n_zz_nn; k < dm.n_zz; ++k) {
+    const double q = dm.zz_q[k];
+    d += (((s >> (dm.zz_i[k] - 1)) ^ (s >> (dm.zz_j[k] - 1))) & 1) ? -q : q;
+  }
   return d;
 }
 

@@ -67,7 +67,7 @@ struct sd_dev_model {
   int n_hop, n_zz;
   int full_ls;           // full 2^L basis, tiled path: a tile is 2^full_ls consecutive rows (0: not in use)
   int nn_hops;           // leading hops that are exactly (1,2),(2,3),...,(L-1,L) in order (L-1 or 0)
-  int diag_mode;         // 0 exact list order, 1 uniform closed form
+  int diag_mode;         // 0 list order with exact term magnitudes (select + add per term), 1 uniform closed form, 2 literal reference loop (SD_DIAG_LITERAL)
   double diag_q;         // Jz/4 for diag_mode 1
   int n_zz_nn;           // leading zz bonds that are the NN chain in order (L-1 or 0), for diag_mode 1
   int field_zero;
@@ -80,6 +80,8 @@ struct sd_dev_model {
   const int *zz_i, *zz_j;
   const double *zz_J;
   const double *field;
+  const double *zz_q;            // (zz_J * 0.5) * 0.5: the exact magnitude of every zz term (diag_mode 0)
+  const double *field_h;         // field * 0.5: the exact magnitude of every field term
   const int64_t *binom;  // (SD_MAX_L+1) x (SD_MAX_L+1) row-major: C(n,k)
   // tiled path tables
   int n_tiles;
@@ -113,6 +115,7 @@ struct sd_model {
   int64_t N = 0;
   std::vector<int> hop_i, hop_j, zz_i, zz_j;
   std::vector<double> hop_J, zz_J, field;
+  std::vector<double> zz_q, field_h;   // device tables of the list-order diagonal (see sd_dev_model)
   std::vector<int64_t> binom;  // host copy
   // plan
   int p = -1, LS = 0;
