@@ -270,7 +270,7 @@ void sd_model_destroy(sd_model *m) {
 int64_t sd_model_dim(const sd_model *m) { return m ? m->N : -1; }
 int sd_model_L(const sd_model *m) { return m ? m->L : -1; }
 int sd_model_nup(const sd_model *m) { return m ? m->nup : -2; }
-int sd_model_path(const sd_model *m) { return !m ? 0 : m->p >= 0 ? 1 : m->full_ls > 0 ? 2 : 0; }
+int sd_model_path(const sd_model *m) { return !m ? 0 : m->p >= 0 ? (m->orb_on ? 3 : 1) : m->full_ls > 0 ? 2 : 0; }
 
 int sd_model_states(const sd_model *m, int64_t start, int64_t count, uint64_t *out) {
   if (!m || !out || start < 0 || count < 0 || start + count > m->N) return SD_EARG;
@@ -518,7 +518,6 @@ int sd_bench_apply_dev(sd_ctx *ctx, const sd_model *m, int dtype, void *buf_a, v
 // mean tile lifetime.  Never used by the product path.
 int sd_debug_phase_profile(sd_ctx *ctx, sd_model *m, int dtype, void *out, const void *psi, double *phases /*8*/) {
   if (!ctx || !m || !m->dev_ready || m->p < 0) return SD_EARG;
-  if (!m->group_P0.empty()) return SD_EARG;   // profile with SD_GROUP_BONDS=0: stamps exist in the single-tile kernel only
   const size_t nt = m->single_prefix.size();
   unsigned long long *d = nullptr;
   SD_HIP(ctx, hipMalloc((void **)&d, nt * 8 * sizeof(unsigned long long)));

@@ -13,7 +13,8 @@
 //  * k_apply_fulltile -- full 2^L basis, L >= 12: idx = state, 2^10 consecutive
 //    rows are a tile; chain bonds inside are LDS reads at i ^ (3 << (a-1)),
 //    higher bonds whole-tile streams from T ^ (3 << b).
-//  * k_apply_grouped  -- experimental (SD_GROUP_BONDS): 4/8 related tiles per workgroup.
+//  * k_apply_orbit (kernels_orbit.hip) -- unsharded open-chain sectors of large systems: 16 tiles related by four
+//    disjoint flippable top bonds per workgroup (their mutual hops never leave the chip).
 //  * k_apply_generic -- any other model (L up to 63, arbitrary bonds, huge
 //    prefix spaces): one row per thread, combinadic unrank / rank per hop.
 // sd_launch_apply picks the path and, for tiled plans with many tiles, issues one
@@ -290,202 +291,9 @@ __global__ __launch_bounds__(BLOCK, 4) void k_apply_tiled(sd_dev_model dm, doubl
   if (epi_has_sums(epi)) {
     double a = sums.s0, b = sums.s1;
     block_reduce2(a, b, red);
-    if (tid == 0) { partials[2 * (size_t)tix] = a; partials[2 * (size_t)tix + 1] = b; }
-  }
-}
-
-// =====================================================================
-// grouped kernel: 8 tiles related by three disjoint flippable top bonds per workgroup
-// =====================================================================
-//
-// The three generator bonds g1<g2<g3 (odd prefix bonds, chosen on the host) map the 8 member tiles onto each other with
-// identical in-tile row order.  All 8 tiles are staged in ONE LDS image, so those three far bonds -- top bonds whose
-// partner tiles never survive in L2 -- are served from LDS: 3 of the ~10 far streams per row disappear for the LDS a
-// three-sites-larger suffix tile would need to save 1.5.  Four teams of 256 threads each process two members; after the
-// single staging barrier the teams run independently (far-bond streams, suffix bonds, store), which overlaps one
-// team's memory phase with another's LDS/VALU phase.  Per-row accumulation order is unchanged (bit-identical results).
-template <int NC, bool FMA, int NGEN>
-__global__ __launch_bounds__(128 << NGEN, 4) void k_apply_grouped(sd_dev_model dm, double *__restrict__ out_,
-                                                        const double *__restrict__ psi_, int epi, sd_epi_args ea,
-                                                        double *__restrict__ partials, int max_len) {
-  using V = typename VT<NC>::type;
-  constexpr int R = 4, TEAM = 256, NMEM = 1 << NGEN, NTEAM = NMEM / 2, NTHR = NTEAM * TEAM;
-  constexpr uint32_t ES = sizeof(V);
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  V *tiles = reinterpret_cast<V *>(smem);                       // NMEM * max_len rows + one all-zero row
-  const int zero_row = NMEM * max_len;
-  int *lbin = reinterpret_cast<int *>(smem + (size_t)(zero_row + 1) * sizeof(V));
-  double *red = reinterpret_cast<double *>(lbin + 16 * SD_BIN_STRIDE);
-
-  const V *__restrict__ psi = reinterpret_cast<const V *>(psi_);
-  const int tid = threadIdx.x;
-  const int team = tid / TEAM, ttid = tid - team * TEAM, lane = tid & 63;
-  const int gix = blockIdx.x;
-  const uint32_t P0 = dm.group_P0[gix];
-  const uint32_t gens = dm.group_gens[gix];
-  const int gb0 = gens & 255, gb1 = (gens >> 8) & 255, gb2 = NGEN > 2 ? (gens >> 16) & 255 : 0;
-  const int p = dm.p, LS = dm.LS;
-  const int t2 = dm.nup - __popc(P0);            // the same for every member
-  const int len = (int)binom_g(dm, LS, t2);
-  const int nU = (int)binom_g(dm, LS - 1, t2 - 1);
-  const uint16_t *__restrict__ sufS = dm.suf_states + dm.suf_off[t2];
-
-  auto member_prefix = [&](int g) {
-    uint32_t P = P0;
-    if (g & 1) P ^= 3u << (gb0 - 1);
-    if (g & 2) P ^= 3u << (gb1 - 1);
-    if (NGEN > 2 && (g & 4)) P ^= 3u << (gb2 - 1);
-    return P;
-  };
-
-  uint32_t sig[R], ioff[R];
-  int irow[R];
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const int i = ttid + r * TEAM;
-    ioff[r] = (uint32_t)i * ES;
-    irow[r] = i < len ? i : len - 1;
-    sig[r] = sufS[irow[r]];
-  }
-
-  // ---- stage the member tiles (each team loads members team and team+NTEAM), one member at a time ----
-#pragma unroll 1
-  for (int mm = 0; mm < 2; ++mm) {
-    const int g = team + NTEAM * mm;
-    const __amdgpu_buffer_rsrc_t rs = make_rsrc(psi + dm.addr[member_prefix(g)], (uint32_t)len * ES);
-    V own[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) buf_load(own[r], rs, ioff[r]);
-#pragma unroll
-    for (int r = 0; r < R; ++r)
-      if (ttid + r * TEAM < len) tiles[g * max_len + irow[r]] = own[r];
-  }
-  if (tid == 0) tiles[zero_row] = V{};
-  for (int k = tid; k < 16 * SD_BIN_STRIDE; k += NTHR) {
-    int n = k / SD_BIN_STRIDE, kk = k - n * SD_BIN_STRIDE;
-    lbin[k] = (int)binom_g(dm, n, kk);
-  }
-  __syncthreads();
-
-  EpiSums sums{0.0, 0.0};
-#pragma unroll 1
-  for (int mm = 0; mm < 2; ++mm) {
-    const int g = team + NTEAM * mm;
-    const uint32_t P = member_prefix(g);
-    const int64_t base = dm.addr[P];
-    const V *__restrict__ tile = tiles + g * max_len;
-
-    // far-bond list of this member: lane b-1 <-> prefix bond b, lane p-1 <-> straddle; generator bonds carry the
-    // LDS row offset of the partner member instead of a global base
-    uint64_t fmask = 0;
-    int64_t my_base = 0;
-    double my_J = 0.0;
-    int my_lo = 0, my_n = len, my_lds = -1;
-    {
-      bool fl = false;
-      const int b = lane + 1;
-      if (b <= p - 1) {
-        fl = ((P >> (b - 1)) ^ (P >> b)) & 1u;
-        if (fl) {
-          my_J = dm.hop_J[b - 1];
-          if (b == gb0) my_lds = (g ^ 1) * max_len;
-          else if (b == gb1) my_lds = (g ^ 2) * max_len;
-          else if (NGEN > 2 && b == gb2) my_lds = (g ^ 4) * max_len;
-          else my_base = dm.addr[P ^ (3u << (b - 1))];
-        }
-      } else if (b == p) {
-        const uint32_t bitp = (P >> (p - 1)) & 1u;
-        const uint32_t Q = P ^ (1u << (p - 1));
-        const int t2q = dm.nup - __popc(Q);
-        if (t2q >= 0 && t2q <= LS) {
-          const int nUq = (int)binom_g(dm, LS - 1, t2q - 1);
-          int64_t shift;
-          if (bitp) { my_lo = nU; my_n = len - nU; shift = 0; }
-          else { my_lo = 0; my_n = nU; shift = nUq; }
-          fl = my_n > 0;
-          if (fl) { my_base = dm.addr[Q] + shift; my_J = dm.hop_J[p - 1]; }
-        }
-      }
-      fmask = __ballot(fl);
-    }
-    struct GB { int64_t base; double J; int lo, n, lds; };
-    auto get_bond = [&](int ln) {
-      GB fb;
-      fb.base = rl64(my_base, ln); fb.J = rld(my_J, ln);
-      fb.lo = rl(my_lo, ln); fb.n = rl(my_n, ln); fb.lds = rl(my_lds, ln);
-      return fb;
-    };
-    auto issue = [&](const GB &fb, V(&v)[R]) {
-      if (fb.lds >= 0) {                                  // generator bond: partner member is in LDS
-        const V *__restrict__ pt = tiles + fb.lds;
-#pragma unroll
-        for (int r = 0; r < R; ++r) v[r] = pt[irow[r]];
-      } else {
-        const __amdgpu_buffer_rsrc_t rs = make_rsrc(psi + fb.base, (uint32_t)fb.n * ES);
-        const uint32_t lo_b = (uint32_t)fb.lo * ES;
-#pragma unroll
-        for (int r = 0; r < R; ++r) buf_load(v[r], rs, ioff[r] - lo_b);
-      }
-    };
-    auto next_lane = [&](uint64_t &m_) { const int ln = __builtin_ctzll(m_); m_ &= m_ - 1; return ln; };
-
-    V va[R], vb[R];
-    GB fa{}, fbb{};
-    uint64_t mk = fmask;
-    bool have_a = false;
-    if (mk) { fa = get_bond(next_lane(mk)); issue(fa, va); have_a = true; }
-
-    V acc[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const uint64_t s = (uint64_t)P | ((uint64_t)sig[r] << p);
-      acc[r] = vscale(diag_of(dm, s), tile[irow[r]]);
-    }
-    while (have_a) {
-      bool have_b = false;
-      if (mk) { fbb = get_bond(next_lane(mk)); issue(fbb, vb); have_b = true; }
-#pragma unroll
-      for (int r = 0; r < R; ++r) acc[r] = accum<FMA>(acc[r], fa.J, va[r]);
-      have_a = false;
-      if (!have_b) break;
-      if (mk) { fa = get_bond(next_lane(mk)); issue(fa, va); have_a = true; }
-#pragma unroll
-      for (int r = 0; r < R; ++r) acc[r] = accum<FMA>(acc[r], fbb.J, vb[r]);
-    }
-
-    // suffix bonds from this member's LDS tile
-    {
-      uint32_t dw[R];
-#pragma unroll
-      for (int r = 0; r < R; ++r) dw[r] = sig[r] ^ (sig[r] >> 1);
-      for (int a = 1; a <= LS - 1; ++a) {
-        const double J = dm.hop_J[p + a - 1];
-        const int *brow = lbin + (LS - a - 1) * SD_BIN_STRIDE;
-        int d[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) d[r] = brow[__popc(sig[r] >> (a + 1))];
-        V v[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-          const bool up = (sig[r] >> (a - 1)) & 1u;
-          const bool fl = (dw[r] >> (a - 1)) & 1u;
-          const int ip = up ? irow[r] + d[r] : irow[r] - d[r];
-          v[r] = fl ? tile[ip] : tiles[zero_row];
-        }
-#pragma unroll
-        for (int r = 0; r < R; ++r) acc[r] = accum<FMA>(acc[r], J, v[r]);
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int i = ttid + r * TEAM;
-      if (i < len) epilogue<NC>(epi, ea, base + i, acc[r], tile[i], out_, sums);
-    }
-  }
-  if (epi_has_sums(epi)) {
-    double a = sums.s0, b = sums.s1;
-    block_reduce2(a, b, red);
-    if (tid == 0) { partials[2 * (size_t)gix] = a; partials[2 * (size_t)gix + 1] = b; }
+    // one pair per tile of the launched PART (interior / boundary launches size the buffer for their own tiles only)
+    const size_t slot = (size_t)(tix - dm.part_off);
+    if (tid == 0) { partials[2 * slot] = a; partials[2 * slot + 1] = b; }
   }
 }
 
@@ -675,7 +483,6 @@ __global__ __launch_bounds__(1024) void k_reduce_pairs(const double *__restrict_
 
 // first stage for long lists (one partial pair per tile: 10^6 pairs at L=32, too long for one workgroup): block j sums
 // the pairs [j*chunk, (j+1)*chunk) into stage[j]; still a fixed order for a given n
-constexpr int SD_RED_STAGE_BLOCKS = 512;
 __global__ __launch_bounds__(256) void k_reduce_pairs_stage(const double *__restrict__ partials, int64_t n, int64_t chunk,
                                                             double *__restrict__ stage) {
   __shared__ double red[32];
@@ -688,7 +495,8 @@ __global__ __launch_bounds__(256) void k_reduce_pairs_stage(const double *__rest
 }
 
 // partials[0 .. 2n) -> ctx->d_scalars[0..1]; the caller reserved 2n + 2*SD_RED_STAGE_BLOCKS doubles of ctx->d_partials
-int reduce_pairs(sd_ctx *ctx, int64_t n, double *dst) {
+}  // namespace
+int sd_reduce_pairs(sd_ctx *ctx, int64_t n, double *dst) {
   if (!dst) dst = ctx->d_scalars;
   const double *src = ctx->d_partials;
   if (n > 16384) {
@@ -702,6 +510,7 @@ int reduce_pairs(sd_ctx *ctx, int64_t n, double *dst) {
   SD_HIP(ctx, hipGetLastError());
   return SD_OK;
 }
+namespace {
 
 template <int NC, int R, int BLOCK, bool FMA>
 int launch_tiled_cfg(sd_ctx *ctx, const sd_dev_model &dm, int nt, size_t shmem, double *out, const double *psi, int epi,
@@ -711,11 +520,9 @@ int launch_tiled_cfg(sd_ctx *ctx, const sd_dev_model &dm, int nt, size_t shmem, 
   // ... and for the SD_DEBUG_SKIP timing ablations: the production instantiations carry no run-time debug branches
   if constexpr (NC == 2 && FMA && (BLOCK == 256 || BLOCK == 128 || BLOCK == 64))
     if (dm.stamps || dm.dbg) kern = k_apply_tiled<NC, R, BLOCK, FMA, true>;
-  static size_t attr_set = 0;
-  if (shmem > 48 * 1024 && shmem > attr_set) {
+  // per kernel AND per device, so no cache: cheap next to a launch, and only the SD_SUFFIX_BITS >= 13 tiles get here
+  if (shmem > 48 * 1024)
     SD_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    attr_set = shmem;
-  }
   hipLaunchKernelGGL(kern, dim3(nt), dim3(BLOCK), shmem, ctx->stream, dm, out, psi, epi, ea, ctx->d_partials, max_len);
   SD_HIP(ctx, hipGetLastError());
   return SD_OK;
@@ -746,34 +553,17 @@ int sd_launch_apply(sd_ctx *ctx, const sd_model *m, int dtype, void *out, const 
   const bool sums = (epi == SD_EPI_DOT || epi == SD_EPI_KPM || epi == SD_EPI_RESCALE_DOT);
   sd_dev_model dm = m->dm;
   if (dm.n_local == 0) return SD_OK;
+  if (m->p >= 0 && m->orb_on && part == 0 && !dm.stamps && !dm.dbg) return sd_launch_apply_orbit(ctx, m, dtype, out, psi, epi, ea);
   if (m->p >= 0) {
     // part 0: every tile; 1: interior tiles only (no halo read); 2: boundary tiles only
     int nt = dm.n_singles;
-    const int ng = part == 0 ? dm.n_groups : 0;
     if (part == 1) nt = dm.n_interior;
     else if (part == 2) nt = dm.n_singles - dm.n_interior;
-    if (sums) { int rc = sd_ensure_partials(ctx, 2 * (size_t)(nt + ng) + 2 * SD_RED_STAGE_BLOCKS); if (rc) return rc; }
+    if (sums) { int rc = sd_ensure_partials(ctx, 2 * (size_t)nt + 2 * SD_RED_STAGE_BLOCKS); if (rc) return rc; }
     const int max_len = m->max_tile_len;
     const size_t esz = dtype == SD_C128 ? 16 : 8;
     int rc = SD_OK;
-    if (ng > 0) {
-      const int ngen = m->group_ngen;
-      const size_t shg = (size_t)((1 << ngen) * max_len + 1) * esz + 16 * SD_BIN_STRIDE * sizeof(int) + 32 * sizeof(double) + 16;
-      void (*kg)(sd_dev_model, double *, const double *, int, sd_epi_args, double *, int);
-      if (ngen == 3)
-        kg = dtype == SD_C128 ? (m->hop_pow2 ? k_apply_grouped<2, true, 3> : k_apply_grouped<2, false, 3>)
-                              : (m->hop_pow2 ? k_apply_grouped<1, true, 3> : k_apply_grouped<1, false, 3>);
-      else
-        kg = dtype == SD_C128 ? (m->hop_pow2 ? k_apply_grouped<2, true, 2> : k_apply_grouped<2, false, 2>)
-                              : (m->hop_pow2 ? k_apply_grouped<1, true, 2> : k_apply_grouped<1, false, 2>);
-      SD_HIP(ctx, hipFuncSetAttribute((const void *)kg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shg));
-      hipLaunchKernelGGL(kg, dim3(ng), dim3(128 << ngen), shg, ctx->stream, dm, (double *)out, (const double *)psi, epi, ea,
-                         ctx->d_partials, max_len);
-      SD_HIP(ctx, hipGetLastError());
-    }
     if (nt > 0) {
-      double *saved = ctx->d_partials;
-      ctx->d_partials = saved ? saved + 2 * (size_t)ng : saved;      // singles write their partials after the groups'
       // one launch per non-empty (part, tile length class) segment; a segment's LDS image is sized by its own longest tile
       const int s0 = part == 2 ? SD_N_LEN_CLASS : 0, s1 = part == 1 ? SD_N_LEN_CLASS : 2 * SD_N_LEN_CLASS;
       for (int sg = s0; sg < s1 && rc == SD_OK; ++sg) {
@@ -792,6 +582,7 @@ int sd_launch_apply(sd_ctx *ctx, const sd_model *m, int dtype, void *out, const 
           if ((size_t)min_kb[cls] * 1024 > shmem) shmem = (size_t)min_kb[cls] * 1024;
         }
         dm.tile_off = m->seg_off[sg];
+        dm.part_off = m->seg_off[s0];
         if (dtype == SD_C128)
           rc = m->hop_pow2 ? launch_tiled<2, true>(ctx, dm, cnt, cls, shmem, (double *)out, (const double *)psi, epi, ea, seg_max)
                            : launch_tiled<2, false>(ctx, dm, cnt, cls, shmem, (double *)out, (const double *)psi, epi, ea, seg_max);
@@ -799,11 +590,10 @@ int sd_launch_apply(sd_ctx *ctx, const sd_model *m, int dtype, void *out, const 
           rc = m->hop_pow2 ? launch_tiled<1, true>(ctx, dm, cnt, cls, shmem, (double *)out, (const double *)psi, epi, ea, seg_max)
                            : launch_tiled<1, false>(ctx, dm, cnt, cls, shmem, (double *)out, (const double *)psi, epi, ea, seg_max);
       }
-      ctx->d_partials = saved;
       if (rc) return rc;
     }
     if (sums) {
-      int rc2 = reduce_pairs(ctx, (int64_t)(nt + ng), ea.sums_dst);
+      int rc2 = sd_reduce_pairs(ctx, (int64_t)nt, ea.sums_dst);
       if (rc2) return rc2;
     }
   } else if (m->full_ls > 0) {
@@ -818,7 +608,7 @@ int sd_launch_apply(sd_ctx *ctx, const sd_model *m, int dtype, void *out, const 
                        ctx->d_partials);
     SD_HIP(ctx, hipGetLastError());
     if (sums) {
-      int rc2 = reduce_pairs(ctx, (int64_t)nb, ea.sums_dst);
+      int rc2 = sd_reduce_pairs(ctx, (int64_t)nb, ea.sums_dst);
       if (rc2) return rc2;
     }
   } else {
@@ -833,7 +623,7 @@ int sd_launch_apply(sd_ctx *ctx, const sd_model *m, int dtype, void *out, const 
                          (const double *)psi, epi, ea, ctx->d_partials);
     SD_HIP(ctx, hipGetLastError());
     if (sums) {
-      int rc2 = reduce_pairs(ctx, (int64_t)nb, ea.sums_dst);
+      int rc2 = sd_reduce_pairs(ctx, (int64_t)nb, ea.sums_dst);
       if (rc2) return rc2;
     }
   }

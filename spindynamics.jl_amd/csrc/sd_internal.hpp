@@ -41,6 +41,20 @@ struct sd_tile_rec {
   int32_t pad0, pad1;
 };
 
+// ---- orbit plan (kernels_orbit.hip): unsharded open-chain sectors of large systems ----
+#define SD_ORB_LS 10      // suffix sites of an orbit-plan tile: C(10,5) = 252 rows, one row per thread of a 256-thread workgroup
+#define SD_ORB_NGEN 4     // generator bonds per orbit: 16 member tiles = 64 KiB of LDS in ComplexF64, two workgroups per CU
+#define SD_ORB_N_CLASS 3  // launch classes by tile length: workgroups of 256 / 128 / 64 threads
+struct sd_orb_rec {      // 64 bytes: everything a workgroup needs to start, fetched with one scalar load
+  int64_t base0;         // first row of the canonical member (every generator pair in state up,down)
+  int64_t dg[SD_ORB_NGEN];   // row offset of flipping generator k (0 when unused)
+  uint32_t P0;           // canonical member's prefix configuration (sites 1..L-SD_ORB_LS)
+  uint32_t gens;         // generator bond numbers, ascending, 6 bits each, 0 = unused
+  int32_t len, nU;       // rows of a member tile, rows whose first suffix site is up
+  int32_t suf_off;       // first row of the tile's suffix sector in orb_ptab
+  int32_t pad;
+};
+
 struct sd_ctx {
   int device = 0;
   hipStream_t own_stream = nullptr;
@@ -95,15 +109,18 @@ struct sd_dev_model {
   const uint16_t *suf_states;    // concatenated sectors (LS, t'), t' = 0..LS
   const int32_t *suf_off;        // LS+2 offsets into suf_states
   const uint16_t *suf_rank;      // 2^LS entries: rank of sigma inside its sector
-  // grouped path: 8 tiles related by three disjoint flippable top bonds share one workgroup / one LDS image
-  int n_groups, n_singles;
+  int n_singles;
   int n_interior;                // sharded plans: the first n_interior single tiles read no halo (their partners are all owned)
   int tile_off;                  // first tile of this launch (lets the interior / boundary parts run as separate launches)
-  const uint32_t *single_prefix; // tiles not in any group (all tiles when grouping is off), processed by k_apply_tiled
+  int part_off;                  // first tile of the launched part: per-tile partial sums are stored relative to it
+  const uint32_t *single_prefix; // the local tiles in launch order (k_apply_tiled)
   const int64_t *single_base;
   const sd_tile_rec *single_rec;
-  const uint32_t *group_P0;      // canonical member prefix (each generator pair in state up,down)
-  const uint32_t *group_gens;    // three generator bonds (1-based), 8 bits each
+  // orbit plan (kernels_orbit.hip)
+  int orb_p;                     // prefix sites of the orbit plan (L - SD_ORB_LS), 0: no orbit plan
+  const sd_orb_rec *orb_groups;  // launch order: class by class, XCD-dealt inside a class
+  const uint32_t *orb_ptab;      // 4 words per (suffix sector, row): bytes 0..LS-2 partner row of suffix bond a (zero row if not flippable), word 3 = suffix configuration
+  const int32_t *orb_suf_off;    // LS+2 offsets of the suffix sectors in orb_ptab (rows)
   unsigned long long *stamps;    // diagnostic builds only (sd_debug_phase_profile): 8 s_memtime stamps per tile, else null
 };
 
@@ -133,15 +150,21 @@ struct sd_model {
   int64_t n_send = 0;           // elements of the packed send buffer (cell mode)
   std::vector<int64_t> pack_src, pack_dst, tile_gbase;
   std::vector<int32_t> pack_len;
-  std::vector<uint32_t> group_P0, group_gens;  // grouped tiles (unsharded NN-chain plans only)
   std::vector<uint32_t> single_prefix;
   int n_interior = 0;
   int seg_off[2 * SD_N_LEN_CLASS + 1] = {0};   // launch segments of the single tiles: (interior | boundary) x length class
   int seg_cls[2 * SD_N_LEN_CLASS] = {0};       // workgroup size of a segment's kernel = 64 << seg_cls
-  int group_ngen = 0;          // generator bonds per group (2 or 3)
   std::vector<int64_t> single_base;
   std::vector<sd_tile_rec> single_rec;
   int max_tile_len = 0;
+  // orbit plan
+  bool orb_on = false;
+  int orb_p = 0;
+  std::vector<sd_orb_rec> orb_groups;
+  int orb_seg_off[SD_ORB_N_CLASS + 1] = {0};
+  int orb_seg_block[SD_ORB_N_CLASS] = {256, 128, 64};
+  std::vector<uint32_t> orb_ptab;
+  std::vector<int32_t> orb_suf_off;
   bool hop_pow2 = false;  // every NN hop amplitude is +-2^k (or 0): J*psi is exact, fma == mul+add
   // device copies
   sd_dev_model dm{};
@@ -184,6 +207,8 @@ struct sd_epi_args {
 // partial sums, the reduced values land in ctx->d_scalars[0..1] (device).
 int sd_launch_apply(sd_ctx *ctx, const sd_model *m, int dtype, void *out, const void *psi, int epi,
                     const sd_epi_args &ea, int part = 0);
+int sd_launch_apply_orbit(sd_ctx *ctx, const sd_model *m, int dtype, void *out, const void *psi, int epi,
+                          const sd_epi_args &ea);
 int sd_launch_observable(sd_ctx *ctx, const sd_model *m, int dtype, const void *psi, int mode, double *out_host);
 int sd_launch_pack(sd_ctx *ctx, const sd_model *m, int dtype, const void *psi, void *sendbuf);
 int sd_launch_fill_randn_local(sd_ctx *ctx, const sd_model *m, int dtype, void *x, uint64_t seed);
@@ -224,6 +249,10 @@ int sd_k_gemv_cols(sd_ctx *ctx, double *y, const double *V, int64_t N, int ncols
 int sd_k_fill_randn(sd_ctx *ctx, double *x, int64_t n, uint64_t seed, uint64_t first);
 double sd_randn_host(uint64_t seed, uint64_t k);
 
+// partials[0 .. 2n) -> dst[0..1] (null: ctx->d_scalars[0..1]) in a fixed order; the caller reserved 2n + 2*SD_RED_STAGE_BLOCKS
+// doubles of ctx->d_partials (long lists are summed in two stages)
+#define SD_RED_STAGE_BLOCKS 512
+int sd_reduce_pairs(sd_ctx *ctx, int64_t n, double *dst);
 // grows ctx->d_partials to at least `doubles` entries (scratch for per-workgroup partial sums)
 int sd_ensure_partials(sd_ctx *ctx, size_t doubles);
 
