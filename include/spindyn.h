@@ -103,8 +103,7 @@ int64_t sd_model_dim(const sd_model *m);      /* length(model.states) */
 int sd_model_L(const sd_model *m);
 int sd_model_nup(const sd_model *m);          /* -1 for the full basis */
 /* which device path the apply takes: 0 generic (per-row rank/unrank), 1 tiled (prefix-run tiles, LDS staged suffix
- * hops), 2 full-basis tiles, 3 orbit groups (16 tiles related by four disjoint top bonds per workgroup; unsharded
- * open-chain sectors of at least 2^24 rows) */
+ * hops), 2 full-basis tiles of 2^10 rows */
 int sd_model_path(const sd_model *m);
 /* model.states[start .. start+count)  (host computation, 0-based start) */
 int sd_model_states(const sd_model *m, int64_t start, int64_t count, uint64_t *states_out);

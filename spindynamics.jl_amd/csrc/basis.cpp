@@ -215,108 +215,9 @@ static void xcd_order(const sd_model *m, int p, std::vector<uint32_t> &tp_io, st
   }
 }
 
-// ---- orbit plan (kernels_orbit.hip) ----
-// Unsharded fixed-nup sectors whose hop list is exactly the open chain.  Tiles of SD_ORB_LS suffix sites; the first
-// SD_ORB_NGEN flippable odd prefix bonds of a tile (pairwise disjoint, so flipping one never changes another) span its
-// orbit; one record per orbit (canonical member: every generator pair in state up,down).  Everything else the kernel
-// needs follows from binomials.  Launch order: one segment per tile-length class (workgroups of 256 / 128 / 64 threads);
-// inside a segment the orbits are sorted by the first row of their canonical member and dealt to the 8 XCDs in runs of
-// SD_ORB_CHUNK consecutive orbits (block b -> XCD b % 8), so that an XCD sweeps 2^NGEN contiguous row windows and the
-// LOW prefix bonds -- whose partner tiles lie inside those windows -- are served by its L2.
-// SD_ORBIT=0 disables the plan, =1 builds it for any size (tests); default: sectors of at least 2^24 rows.
-static void build_orbit_plan(sd_model *m) {
-  m->orb_on = false; m->orb_p = 0;
-  m->orb_groups.clear(); m->orb_ptab.clear(); m->orb_suf_off.clear();
-  int want = -1;
-  if (const char *e = getenv("SD_ORBIT")) want = atoi(e);
-  const int L = m->L, LS = SD_ORB_LS, p = L - LS, nn = count_nn_hops(m);
-  if (want == 0 || m->nranks != 1 || m->nup < 0 || m->p < 0) return;
-  if (nn == 0 || (int)m->hop_i.size() != nn) return;            // open chain only: every hop is one of the L-1 chain bonds
-  if (p < 3 || p > 26 || L - 1 > 63) return;
-  if (want < 0 && m->N < ((int64_t)1 << 24)) return;
-
-  // per-(suffix sector, row) table: partner row of every suffix bond, suffix configuration
-  std::vector<uint16_t> st;
-  m->orb_suf_off.assign(LS + 2, 0);
-  for (int t = 0; t <= LS; ++t) {
-    m->orb_suf_off[t] = (int32_t)st.size();
-    enum_sector(LS, t, st);
-  }
-  m->orb_suf_off[LS + 1] = (int32_t)st.size();
-  auto block_of = [&](int64_t len) { return len < 64 ? 64 : (len < 128 ? 128 : 256); };   // strictly longer than the tile: row BLOCK-1 is a zero row
-  m->orb_ptab.assign(st.size() * 4, 0);
-  for (int t = 0; t <= LS; ++t) {
-    const int32_t off = m->orb_suf_off[t], n = m->orb_suf_off[t + 1] - off;
-    const uint32_t none = (uint32_t)block_of(n) - 1;
-    for (int32_t i = 0; i < n; ++i) {
-      const uint32_t sig = st[off + i];
-      uint32_t w[4] = {0, 0, 0, sig};
-      for (int a = 1; a <= LS - 1; ++a) {
-        uint32_t pr = none;
-        if (((sig >> (a - 1)) ^ (sig >> a)) & 1u) {
-          const int64_t d = B(m, LS - a - 1, __builtin_popcount(sig >> (a + 1)));
-          pr = (uint32_t)(((sig >> (a - 1)) & 1u) ? i + d : i - d);
-        }
-        w[(a - 1) >> 2] |= pr << (8 * ((a - 1) & 3));
-      }
-      for (int q = 0; q < 4; ++q) m->orb_ptab[(size_t)(off + i) * 4 + q] = w[q];
-    }
-  }
-
-  // orbits, by length class
-  std::vector<sd_orb_rec> cls[SD_ORB_N_CLASS];
-  const uint32_t nP = 1u << p;
-  for (uint32_t P = 0; P < nP; ++P) {
-    const int t2 = m->nup - __builtin_popcount(P);
-    if (t2 < 0 || t2 > LS) continue;
-    sd_orb_rec rec{};
-    int ng = 0; bool canonical = true;
-    for (int b = 1; b + 1 <= p && ng < SD_ORB_NGEN; b += 2)
-      if (((P >> (b - 1)) ^ (P >> b)) & 1u) {
-        if (!((P >> (b - 1)) & 1u)) { canonical = false; break; }
-        rec.gens |= (uint32_t)b << (6 * ng);
-        // flipping (up,down) -> (down,up) on bond b moves a row by C(L-b-1, u), u = up spins beyond site b+1
-        rec.dg[ng] = B(m, L - b - 1, m->nup - __builtin_popcount(P & (uint32_t)(((uint64_t)1 << (b + 1)) - 1)));
-        ++ng;
-      }
-    if (!canonical) continue;
-    int64_t base = 0; int r = m->nup;
-    for (int k = 1; k <= p && r > 0; ++k) {
-      if ((P >> (k - 1)) & 1) --r;
-      else base += B(m, L - k, r - 1);
-    }
-    const int blk = block_of(B(m, LS, t2));
-    rec.base0 = base; rec.P0 = P;
-    rec.len = (int32_t)B(m, LS, t2); rec.nU = (int32_t)B(m, LS - 1, t2 - 1); rec.suf_off = m->orb_suf_off[t2];
-    cls[blk == 256 ? 0 : (blk == 128 ? 1 : 2)].push_back(rec);
-  }
-  int CH = 64;
-  if (const char *e = getenv("SD_ORB_CHUNK")) CH = std::max(1, atoi(e));
-  for (int c = 0; c < SD_ORB_N_CLASS; ++c) {
-    m->orb_seg_off[c] = (int)m->orb_groups.size();
-    m->orb_seg_block[c] = 256 >> c;
-    auto &v = cls[c];
-    std::sort(v.begin(), v.end(), [](const sd_orb_rec &a, const sd_orb_rec &b) { return a.base0 < b.base0; });
-    // position j of XCD queue x -> block 8j + x; queue x holds the runs x, x+8, x+16, ... of CH consecutive orbits
-    const size_t n = v.size(), group = (size_t)8 * CH, full = n / group * group;
-    for (size_t b = 0; b < n; ++b) {
-      size_t t = b;
-      if (b < full) {
-        const size_t x = b % 8, sl = b / 8, g = sl / CH, i = sl % CH;
-        t = g * group + x * CH + i;
-      }
-      m->orb_groups.push_back(v[t]);
-    }
-  }
-  m->orb_seg_off[SD_ORB_N_CLASS] = (int)m->orb_groups.size();
-  m->orb_p = p;
-  m->orb_on = !m->orb_groups.empty();
-}
-
 int sd_build_plan(sd_model *m, int rank, int nranks, std::string &err) {
   if (nranks < 1 || rank < 0 || rank >= nranks) { err = "bad shard rank/nranks"; return SD_EARG; }
   m->rank = rank; m->nranks = nranks;
-  m->orb_on = false; m->orb_p = 0; m->orb_groups.clear();
   m->tile_prefix.clear(); m->tile_base.clear(); m->addr.clear();
   m->suf_states.clear(); m->suf_rank.clear(); m->suf_off.clear();
   m->recv_slabs.clear(); m->send_slabs.clear();
@@ -582,7 +483,6 @@ int sd_build_plan(sd_model *m, int rank, int nranks, std::string &err) {
   }
   m->tile_gbase.resize(m->tile_prefix.size());
   for (size_t k = 0; k < m->tile_prefix.size(); ++k) m->tile_gbase[k] = tile_base_global(m, m->tile_prefix[k]);
-  build_orbit_plan(m);
   return SD_OK;
 }
 
@@ -693,10 +593,6 @@ int sd_upload_model(sd_model *m, std::string &err) {
       r.len = (int32_t)B(m, m->LS, t2); r.nU = (int32_t)B(m, m->LS - 1, t2 - 1); r.suf_off = m->suf_off[t2];
       r.pad0 = r.pad1 = 0;
     }
-    d.orb_p = m->orb_on ? m->orb_p : 0;
-    if ((rc = up(m, m->orb_groups, &d.orb_groups, err))) return rc;
-    if ((rc = up(m, m->orb_ptab, &d.orb_ptab, err))) return rc;
-    if ((rc = up(m, m->orb_suf_off, &d.orb_suf_off, err))) return rc;
     if ((rc = up(m, m->single_rec, &d.single_rec, err))) return rc;
     if ((rc = up(m, m->single_prefix, &d.single_prefix, err))) return rc;
     if ((rc = up(m, m->single_base, &d.single_base, err))) return rc;

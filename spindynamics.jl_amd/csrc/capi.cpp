@@ -270,7 +270,7 @@ void sd_model_destroy(sd_model *m) {
 int64_t sd_model_dim(const sd_model *m) { return m ? m->N : -1; }
 int sd_model_L(const sd_model *m) { return m ? m->L : -1; }
 int sd_model_nup(const sd_model *m) { return m ? m->nup : -2; }
-int sd_model_path(const sd_model *m) { return !m ? 0 : m->p >= 0 ? (m->orb_on ? 3 : 1) : m->full_ls > 0 ? 2 : 0; }
+int sd_model_path(const sd_model *m) { return !m ? 0 : m->p >= 0 ? 1 : m->full_ls > 0 ? 2 : 0; }
 
 int sd_model_states(const sd_model *m, int64_t start, int64_t count, uint64_t *out) {
   if (!m || !out || start < 0 || count < 0 || start + count > m->N) return SD_EARG;

@@ -13,8 +13,6 @@
 //  * k_apply_fulltile -- full 2^L basis, L >= 12: idx = state, 2^10 consecutive
 //    rows are a tile; chain bonds inside are LDS reads at i ^ (3 << (a-1)),
 //    higher bonds whole-tile streams from T ^ (3 << b).
-//  * k_apply_orbit (kernels_orbit.hip) -- unsharded open-chain sectors of large systems: 16 tiles related by four
-//    disjoint flippable top bonds per workgroup (their mutual hops never leave the chip).
 //  * k_apply_generic -- any other model (L up to 63, arbitrary bonds, huge
 //    prefix spaces): one row per thread, combinadic unrank / rank per hop.
 // sd_launch_apply picks the path and, for tiled plans with many tiles, issues one
@@ -553,7 +551,6 @@ int sd_launch_apply(sd_ctx *ctx, const sd_model *m, int dtype, void *out, const 
   const bool sums = (epi == SD_EPI_DOT || epi == SD_EPI_KPM || epi == SD_EPI_RESCALE_DOT);
   sd_dev_model dm = m->dm;
   if (dm.n_local == 0) return SD_OK;
-  if (m->p >= 0 && m->orb_on && part == 0 && !dm.stamps && !dm.dbg) return sd_launch_apply_orbit(ctx, m, dtype, out, psi, epi, ea);
   if (m->p >= 0) {
     // part 0: every tile; 1: interior tiles only (no halo read); 2: boundary tiles only
     int nt = dm.n_singles;

@@ -41,20 +41,6 @@ struct sd_tile_rec {
   int32_t pad0, pad1;
 };
 
-// ---- orbit plan (kernels_orbit.hip): unsharded open-chain sectors of large systems ----
-#define SD_ORB_LS 10      // suffix sites of an orbit-plan tile: C(10,5) = 252 rows, one row per thread of a 256-thread workgroup
-#define SD_ORB_NGEN 4     // generator bonds per orbit: 16 member tiles = 64 KiB of LDS in ComplexF64, two workgroups per CU
-#define SD_ORB_N_CLASS 3  // launch classes by tile length: workgroups of 256 / 128 / 64 threads
-struct sd_orb_rec {      // 64 bytes: everything a workgroup needs to start, fetched with one scalar load
-  int64_t base0;         // first row of the canonical member (every generator pair in state up,down)
-  int64_t dg[SD_ORB_NGEN];   // row offset of flipping generator k (0 when unused)
-  uint32_t P0;           // canonical member's prefix configuration (sites 1..L-SD_ORB_LS)
-  uint32_t gens;         // generator bond numbers, ascending, 6 bits each, 0 = unused
-  int32_t len, nU;       // rows of a member tile, rows whose first suffix site is up
-  int32_t suf_off;       // first row of the tile's suffix sector in orb_ptab
-  int32_t pad;
-};
-
 struct sd_ctx {
   int device = 0;
   hipStream_t own_stream = nullptr;
@@ -116,11 +102,6 @@ struct sd_dev_model {
   const uint32_t *single_prefix; // the local tiles in launch order (k_apply_tiled)
   const int64_t *single_base;
   const sd_tile_rec *single_rec;
-  // orbit plan (kernels_orbit.hip)
-  int orb_p;                     // prefix sites of the orbit plan (L - SD_ORB_LS), 0: no orbit plan
-  const sd_orb_rec *orb_groups;  // launch order: class by class, XCD-dealt inside a class
-  const uint32_t *orb_ptab;      // 4 words per (suffix sector, row): bytes 0..LS-2 partner row of suffix bond a (zero row if not flippable), word 3 = suffix configuration
-  const int32_t *orb_suf_off;    // LS+2 offsets of the suffix sectors in orb_ptab (rows)
   unsigned long long *stamps;    // diagnostic builds only (sd_debug_phase_profile): 8 s_memtime stamps per tile, else null
 };
 
@@ -157,14 +138,6 @@ struct sd_model {
   std::vector<int64_t> single_base;
   std::vector<sd_tile_rec> single_rec;
   int max_tile_len = 0;
-  // orbit plan
-  bool orb_on = false;
-  int orb_p = 0;
-  std::vector<sd_orb_rec> orb_groups;
-  int orb_seg_off[SD_ORB_N_CLASS + 1] = {0};
-  int orb_seg_block[SD_ORB_N_CLASS] = {256, 128, 64};
-  std::vector<uint32_t> orb_ptab;
-  std::vector<int32_t> orb_suf_off;
   bool hop_pow2 = false;  // every NN hop amplitude is +-2^k (or 0): J*psi is exact, fma == mul+add
   // device copies
   sd_dev_model dm{};
@@ -207,8 +180,6 @@ struct sd_epi_args {
 // partial sums, the reduced values land in ctx->d_scalars[0..1] (device).
 int sd_launch_apply(sd_ctx *ctx, const sd_model *m, int dtype, void *out, const void *psi, int epi,
                     const sd_epi_args &ea, int part = 0);
-int sd_launch_apply_orbit(sd_ctx *ctx, const sd_model *m, int dtype, void *out, const void *psi, int epi,
-                          const sd_epi_args &ea);
 int sd_launch_observable(sd_ctx *ctx, const sd_model *m, int dtype, const void *psi, int mode, double *out_host);
 int sd_launch_pack(sd_ctx *ctx, const sd_model *m, int dtype, const void *psi, void *sendbuf);
 int sd_launch_fill_randn_local(sd_ctx *ctx, const sd_model *m, int dtype, void *x, uint64_t seed);

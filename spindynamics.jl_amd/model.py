@@ -80,7 +80,7 @@ class Model:
 
     @property
     def device_path(self):
-        return {1: "tiled", 2: "full-tiled", 3: "orbit"}.get(lib().sd_model_path(self.h), "generic")
+        return {1: "tiled", 2: "full-tiled"}.get(lib().sd_model_path(self.h), "generic")
 
     # -- sharding --
     def set_shard(self, rank, nranks, mode=None):
