@@ -19,26 +19,48 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0      # MI355X spec HBM3E peak (MI355X_MICROARCH.md); measured float4-copy ceiling 6290 GB/s
+HBM_PEAK_GBS = 8000.0      # MI355X spec HBM3E peak (MI355X_MICROARCH.md)
+HBM_COPY_GBS = 6290.0      # the guide's measured float4-copy ceiling: quoted beside the spec fraction
 SEED = 20260821
+# sources whose change invalidates a committed PMC traffic figure (profiles/collect_traffic.py stamps their hash)
+TRAFFIC_SOURCES = ["spindynamics.jl_amd/csrc/kernels_apply.hip", "spindynamics.jl_amd/csrc/device_common.hpp",
+                   "spindynamics.jl_amd/csrc/basis.cpp", "spindynamics.jl_amd/csrc/sd_internal.hpp"]
+
+
+def kernel_source_hash():
+    import hashlib
+    h = hashlib.sha256()
+    for rel in TRAFFIC_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def cpu_baseline(L, nup, budget_s=20.0):
-    """The C oracle (a port of the reference's algorithm: states[] + hash map, row-owner gather) timed on the
-    host cores on a bounded sample: the same model family at a smaller L, scaled to L=32 rows."""
+    """The C oracle (a port of the reference's algorithm: states[] + hash map, row-owner gather; Julia is absent on the
+    box) timed on the host cores on a bounded sample: the same model family at L=28, scaled to
+    L=32 rows.  Falls back to L=26 only when one L=28 apply alone would exceed the budget, and says so."""
     import numpy as np
     from oracle import oracle as O
     from math import comb
-    Ls = int(os.environ.get("SD_BENCH_CPU_L", "26"))
+    Ls = int(os.environ.get("SD_BENCH_CPU_L", "28"))
     # the GPU box gives one GPU a 16-core CPU share; more OpenMP threads than that only oversubscribe
     ncores = int(os.environ.get("SD_BENCH_CPU_THREADS", str(min(16, os.cpu_count() or 1))))
     O.set_num_threads(ncores)
-    t0 = time.time()
-    m = O.XXZChain(Ls, nup=Ls // 2)
-    build_s = time.time() - t0
-    rng = np.random.default_rng(1)
-    psi = rng.standard_normal(m.N) + 1j * rng.standard_normal(m.N)
-    O.apply_H(m, psi)  # warm
+    note = ""
+    while True:
+        t0 = time.time()
+        m = O.XXZChain(Ls, nup=Ls // 2)
+        build_s = time.time() - t0
+        rng = np.random.default_rng(1)
+        psi = rng.standard_normal(m.N) + 1j * rng.standard_normal(m.N)
+        t0 = time.time()
+        O.apply_H(m, psi)  # warm
+        first = time.time() - t0
+        if first <= budget_s or Ls <= 26:
+            break
+        note = "; L=%d dropped: one apply took %.1f s > the %.0f s budget" % (Ls, first, budget_s)
+        Ls = 26
     reps, t0 = 0, time.time()
     while True:
         O.apply_H(m, psi)
@@ -52,18 +74,20 @@ def cpu_baseline(L, nup, budget_s=20.0):
         "value": rows_per_s / n_full,
         "unit": "matvecs/s (L=32-equivalent, rows/s scaled by N)",
         "cores": O.num_threads(),
+        "host_cpu_count": os.cpu_count(),
         "kind": "port",
         "sample": f"oracle so_apply_H, XXZChain(L={Ls},nup={Ls // 2}) c128, N={m.N}, {reps} applies, "
-                  f"{dt * 1e3:.1f} ms each ({rows_per_s / 1e6:.1f} Mrows/s); basis+hash build {build_s:.1f} s; "
-                  f"extrapolated proportional to N (optimistic for the CPU: its hash map leaves cache at L=32)",
+                  f"{dt * 1e3:.1f} ms each ({rows_per_s / 1e6:.1f} Mrows/s) on {O.num_threads()} of {os.cpu_count()} host "
+                  f"cores; basis+hash build {build_s:.1f} s; extrapolated proportional to N (optimistic for the CPU: its "
+                  f"hash map leaves cache at L=32){note}",
     }
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--L", type=int, default=int(os.environ.get("SD_BENCH_L", "32")))
     ap.add_argument("--dtype", default="c128", choices=["c128", "f64"])
     ap.add_argument("--no-cpu", action="store_true")
@@ -182,13 +206,20 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         alg_bytes = op.n_local * 2 * esize               # read psi[idx] once + write out[idx] once
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9    # GB/s on this rank's GPU
-        traffic = None
+        # HBM-side bytes per apply from the PMC counters (2*FETCH_SIZE + WRITE_SIZE, gfx950 correction): collected by
+        # profiles/run_profile.sh in separate rocprofv3 passes and committed with the hash of the kernel sources it was
+        # measured on.  A figure measured on other sources is not reported.
+        traffic, traffic_source = None, "no PMC figure for this workload (profiles/traffic_latest.json)"
         tp = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tp):
             try:
                 tj = json.load(open(tp))
                 if tj.get("L") == L and tj.get("dtype") == args.dtype and world == 1:
-                    traffic = tj.get("hbm_bytes_per_launch")
+                    if tj.get("source_hash") == kernel_source_hash():
+                        traffic = tj.get("hbm_bytes_per_launch")
+                        traffic_source = "profiles/traffic_latest.json, measured on these kernel sources (hash %s)" % tj.get("source_hash")
+                    else:
+                        traffic_source = "profiles/traffic_latest.json is stale (kernel sources changed since it was measured): null"
             except Exception:
                 traffic = None
         line = {
@@ -212,7 +243,8 @@ def main():
             "selfcheck": check,
             "achieved_hbm_GBs_per_gpu": achieved,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "frac_of_copy_ceiling": achieved / HBM_COPY_GBS,
+                         "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": ("k_apply_tiled<c128>" if args.dtype == "c128" else "k_apply_tiled<f64>")
                                    + " (one launch per tile length class; all of them timed and counted together)",
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes},

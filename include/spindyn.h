@@ -43,6 +43,7 @@ extern "C" {
 #define SD_EHIP 5
 #define SD_ENODEV 6
 #define SD_EINTERNAL 7
+#define SD_ECOMM 8   /* RCCL / exchange callback failure */
 
 #define SD_F64 1
 #define SD_C128 2
@@ -305,6 +306,65 @@ int sd_apply_sharded_cheb2_dev(sd_ctx *ctx, const sd_model *m, void *out, const 
                                const void *phi_prev, void *psi_t, int part);
 int sd_model_shard_info(const sd_model *m, sd_shard_info *out);
 int sd_model_shard_slabs(const sd_model *m, sd_slab *recv_out, sd_slab *send_out);
+
+/* ---- sharded recursions (one process per GPU) ------------------------------------------------------------------
+ * The reference has no distributed layer (its only parallel construct above apply_H! is the thread loop over the momenta,
+ * src/KPM_Sqw.jl:218).  These are the recursion-level entry points of above for a model re-planned with
+ * sd_model_set_shard[_mode]: every vector argument is this rank's OWNED part (n_local elements, device pointer), every
+ * rank makes the same call, scalars come back identical on all ranks.  A sd_comm says how halos travel and scalars are
+ * summed; with the RCCL communicator a recursion step (pack, grouped send/recv beside the interior tiles, boundary tiles,
+ * BLAS-1 passes, ncclAllReduce of the device scalars) is queued without touching the host.  Halo and send buffers come
+ * from the context's pool: per rank a recursion holds its vectors (n_local elements each) + n_halo + n_send elements. */
+typedef struct sd_comm sd_comm;
+typedef struct sd_comm_callbacks {
+  void *user;
+  /* Post the halo exchange: for every send slab of this rank (sd_model_shard_slabs) send src_dev[local_offset ..
+   * local_offset+count) to slab.peer, for every recv slab receive into halo_dev[local_offset - n_local ..).  src_dev is the
+   * vector itself (mode 0) or the packed send buffer (mode 1); elements are dtype-sized; both are device pointers whose
+   * producers are queued on the context's stream.  May return before the bytes have moved. */
+  int (*exchange_start)(void *user, int dtype, const void *src_dev, void *halo_dev);
+  /* Return once work queued on the context's stream after this call is ordered behind the completed exchange. */
+  int (*exchange_wait)(void *user);
+  /* vals[0..count) <- sum over all ranks (host memory; count <= 16). */
+  int (*allreduce_sum)(void *user, double *vals, int count);
+} sd_comm_callbacks;
+/* nonzero return of a callback aborts the call with SD_ECOMM */
+int sd_comm_from_callbacks(const sd_comm_callbacks *cb, int rank, int nranks, sd_comm **out);
+/* RCCL over xGMI.  Rank 0 obtains a 128-byte id (ncclGetUniqueId) and hands it to the other ranks by any means (the
+ * Julia front-end: Distributed / MPI; the Python mirror: torch.distributed broadcast); every rank then creates its
+ * communicator on its context's device.  Collective: all nranks must call. */
+int sd_comm_rccl_unique_id(void *id128);
+int sd_comm_rccl_create(sd_ctx *ctx, int rank, int nranks, const void *id128, sd_comm **out);
+void sd_comm_destroy(sd_comm *comm);
+/* Diagnostic (RCCL communicator): ncclAllReduce of two device doubles and a grouped ncclSend/ncclRecv to this rank itself,
+ * bytes checked.  Needs no peer with nranks == 1; with more ranks all of them must call it. */
+int sd_comm_selftest(sd_ctx *ctx, sd_comm *comm);
+
+/* out = H psi on the owned rows, halo exchange included (overlapped with the interior tiles when overlap != 0). */
+int sd_apply_sharded(sd_ctx *ctx, const sd_model *m, sd_comm *comm, int dtype, void *out_dev, const void *psi_dev,
+                     int64_t n_local, int overlap);
+/* lanczos_extremal / estimate_energy_bounds (src/Lanczos.jl:27-84, 255-271); psi0_dev NULL: counter-based N(0,1) start
+ * vector keyed by the global row index (the same state for every sharding). */
+int sd_lanczos_extremal_sharded(sd_ctx *ctx, const sd_model *m, sd_comm *comm, int lanc_m, double tol, const void *psi0_dev,
+                                uint64_t seed, int negate, double *emin, double *emax);
+int sd_energy_bounds_sharded(sd_ctx *ctx, const sd_model *m, sd_comm *comm, int lanc_m, uint64_t seed, double *Emin,
+                             double *Emax);
+/* chebyshev_time_evolve (src/TimeEvolution/Chebyshev.jl:61-124) on ComplexF64 shards; psit_dev may alias psi0_dev. */
+int sd_chebyshev_evolve_sharded(sd_ctx *ctx, const sd_model *m, sd_comm *comm, const void *psi0_dev, int64_t n_local,
+                                double dt, int cheb_n, double Emin, double Emax, void *psit_dev);
+/* krylov_time_evolve (src/TimeEvolution/Krylov.jl:136-192) on shards (psit ComplexF64). */
+int sd_krylov_evolve_sharded(sd_ctx *ctx, const sd_model *m, sd_comm *comm, int dtype, const void *psi0_dev,
+                             int64_t n_local, double dt, int kry_m, void *psit_dev);
+/* compute_chebyshev_moments (src/KPM_Sqw.jl:95-128): phi_dev normalised over all ranks; mu (host, M entries) on every rank. */
+int sd_kpm_moments_sharded(sd_ctx *ctx, const sd_model *m, sd_comm *comm, const void *phi_dev, int64_t n_local, int M,
+                           double a, double b, double *mu);
+/* kpm_sqw (src/KPM_Sqw.jl:191-256) on a sharded psi0 (BASELINE config 5); Smat (host, Qn x W row-major) on every rank. */
+int sd_kpm_sqw_sharded(sd_ctx *ctx, const sd_model *m, sd_comm *comm, int dtype, const void *psi0_dev, int64_t n_local,
+                       const double *q, int Qn, const double *omega, int W, int have_ab, double a, double b, int kpm_m,
+                       int kernel, uint64_t seed, double *Smat);
+/* <x|y> (re, im) and |x|^2 over all ranks */
+int sd_dot_sharded(sd_ctx *ctx, sd_comm *comm, int dtype, const void *x_dev, const void *y_dev, int64_t n_local,
+                   double *out2);
 
 #ifdef __cplusplus
 }

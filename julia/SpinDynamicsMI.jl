@@ -15,6 +15,8 @@
 #   groundstate, time_evolve, dynamical_structure_factor   src/PublicAPI.jl:25-155
 module SpinDynamicsMI
 
+using Random
+
 export Model, build_model, XXZChain, momenta, apply_H!, apply_rescaled_H!, Sz_q_vector, create_spin_operator,
        groundstate, time_evolve, structure_factor, dynamical_structure_factor,
        magnetization_per_site, connected_correlations, structure_factor_Sq,
@@ -138,7 +140,7 @@ const _SPIN_OPS = Dict(:z => 0, :plus => 1, :minus => 2, :x => 3, :y => 4)
 function create_spin_operator(site::Int, op_type::Symbol)
     site >= 1 || throw(ArgumentError("site must be at least 1"))
     haskey(_SPIN_OPS, op_type) ||
-        throw(ArgumentError("unsupported spin operator: \$op_type; expected :z, :plus, :minus, :x, or :y"))
+        throw(ArgumentError("unsupported spin operator: $op_type; expected :z, :plus, :minus, :x, or :y"))
     function operator(ψ::AbstractVector{T}, model::Model) where {T}
         x = T <: Complex ? Vector{ComplexF64}(ψ) : Vector{Float64}(ψ)
         out = similar(x)
@@ -186,28 +188,43 @@ polarized_state(model::Model; up::Bool=true) = _one_hot(model, up ? 2 : 3)
 polarized_state_with_flips(model::Model, flips::Vector{Int}) = _one_hot(model, 4, flips)
 
 # ---- PublicAPI (src/PublicAPI.jl) ---------------------------------------------------
+# Start vectors: the reference draws them with randn(rng, T, N) (src/Lanczos.jl:39,99).  With `rng` (default
+# Random.default_rng(), as in the reference) the shim draws the same vector in Julia and hands it to the library, so the
+# reference's random stream -- and with it every un-converged Lanczos output -- is reproduced.  `seed=k` selects the
+# library's counter-based device generator instead (no host vector: the choice for L >= 30); `psi0=v` injects a vector.
 function groundstate(model::Model; method::Symbol=:lanczos, lanc_m::Int=100, tol::Float64=1e-12,
-                     orthogonalize_tol::Float64=1e-10, psi0::Union{Nothing,Vector{Float64}}=nothing, seed::Integer=0)
+                     orthogonalize_tol::Float64=1e-10, rng::AbstractRNG=Random.default_rng(),
+                     psi0::Union{Nothing,Vector{Float64}}=nothing, seed::Union{Nothing,Integer}=nothing)
     method === :lanczos || throw(ArgumentError("unsupported ground-state method: $method"))
     N = length(model)
+    if psi0 === nothing && seed === nothing
+        psi0 = randn(rng, Float64, N)                                   # src/Lanczos.jl:99
+    end
     E0 = Ref{Float64}(0.0); mact = Ref{Cint}(0)
     gs = Vector{Float64}(undef, N)
     check(ccall((:sd_lanczos_groundstate, libspindyn), Cint,
                 (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Float64, Float64, Ptr{Float64}, UInt64, Ref{Float64}, Ptr{Float64}, Ref{Cint}),
-                model.ctx.h, model.h, lanc_m, tol, orthogonalize_tol, psi0 === nothing ? C_NULL : psi0, seed, E0, gs, mact), model.ctx.h)
+                model.ctx.h, model.h, lanc_m, tol, orthogonalize_tol, psi0 === nothing ? C_NULL : psi0,
+                seed === nothing ? 0 : seed, E0, gs, mact), model.ctx.h)
     return E0[], gs
 end
 
-function estimate_energy_bounds(model::Model; lanc_m::Int=80, seed::Integer=0)
+# estimate_energy_bounds does not forward rng in the reference either (src/Lanczos.jl:258,267): both Lanczos runs draw
+# from Random.default_rng()
+function estimate_energy_bounds(model::Model; lanc_m::Int=80, seed::Union{Nothing,Integer}=nothing)
     lo = Ref{Float64}(0.0); hi = Ref{Float64}(0.0)
+    N = length(model)
+    va = seed === nothing ? randn(Random.default_rng(), ComplexF64, N) : nothing     # src/Lanczos.jl:39
+    vb = seed === nothing ? randn(Random.default_rng(), ComplexF64, N) : nothing
     check(ccall((:sd_energy_bounds, libspindyn), Cint,
                 (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, UInt64, Ref{Float64}, Ref{Float64}),
-                model.ctx.h, model.h, lanc_m, C_NULL, C_NULL, seed, lo, hi), model.ctx.h)
+                model.ctx.h, model.h, lanc_m, va === nothing ? C_NULL : va, vb === nothing ? C_NULL : vb,
+                seed === nothing ? 0 : seed, lo, hi), model.ctx.h)
     return lo[], hi[]
 end
 
 function time_evolve(model::Model, ψ0::AbstractVector, t::Real; method::Symbol=:krylov, Ebounds=nothing,
-                     kry_m::Int=30, cheb_n::Int=100, seed::Integer=0)
+                     kry_m::Int=30, cheb_n::Int=100, seed::Union{Nothing,Integer}=nothing)
     N = length(ψ0)
     out = Vector{ComplexF64}(undef, N)
     if method === :krylov

@@ -1,5 +1,5 @@
-"""End-to-end rehearsal of the sharded drivers with several REAL processes sharing one GPU (gloo; the halo messages are
-staged through the host, see dist.py): every rank owns a shard of the state, and its owned rows of
+"""End-to-end rehearsal of the sharded recursion-level C entry points (sd_*_sharded behind dist.ShardedOperator) with several
+REAL processes sharing one GPU (gloo behind the sd_comm callbacks; the halo messages are staged through the host): every rank owns a shard of the state, and its owned rows of
   apply, chebyshev_time_evolve, kpm_moments (two per apply and the reference loop), lanczos_extremal, S(q,w)
 must equal what the unsharded single-GPU path gives.  Launch:
   python -m torch.distributed.run --nnodes=1 --nproc-per-node 3 --master-addr 127.0.0.1 --master-port 29544 profiles/sharded_rehearsal.py"""
@@ -38,7 +38,11 @@ for mode in ("class", "range"):
     for cn in (9, 12):
         ref = pkg.chebyshev_time_evolve(psi, 0.3, pkg.apply_H, full, cheb_n=cn, Ebounds=(-8.5, 5.0))
         got = op.chebyshev_time_evolve(mine, 0.3, cheb_n=cn, Ebounds=(-8.5, 5.0)).cpu().numpy()
-        ok &= bool(np.abs(got - ref[rows]).max() <= 1e-15)
+        ok &= bool(np.array_equal(got, ref[rows]))          # no reduction inside: bit-identical to the single-GPU recursion
+    # Krylov step (alpha_j, beta_j summed over the ranks: agreement to rounding, not to the bit)
+    ref = pkg.krylov_time_evolve(psi, 0.2, pkg.apply_H, full, kry_m=12)
+    got = op.krylov_time_evolve(mine, 0.2, kry_m=12).cpu().numpy()
+    ok &= bool(np.abs(got - ref[rows]).max() <= 1e-12)
     # KPM moments
     a, b = L / 2 + 1.0, 0.0
     mu_ref = pkg.compute_chebyshev_moments(pkg.apply_H, psi, 21, a, b, full)

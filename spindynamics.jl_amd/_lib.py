@@ -11,7 +11,7 @@ import sys
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SD_LIB_PATH") or os.path.join(_PKG, "libspindyn.so")   # SD_LIB_PATH: A/B builds of the same ABI
 
-SD_OK, SD_EARG, SD_EDIM, SD_EZERO, SD_ENOMEM, SD_EHIP, SD_ENODEV, SD_EINTERNAL = range(8)
+SD_OK, SD_EARG, SD_EDIM, SD_EZERO, SD_ENOMEM, SD_EHIP, SD_ENODEV, SD_EINTERNAL, SD_ECOMM = range(9)
 SD_F64, SD_C128 = 1, 2
 KERNELS = {"jackson": 0, "lorentz": 1}
 BROADEN = {"lorentz": 0, "gauss": 1}
@@ -44,6 +44,17 @@ class sd_shard_info(C.Structure):
 
 class sd_slab(C.Structure):
     _fields_ = [("peer", C.c_int), ("local_offset", C.c_int64), ("count", C.c_int64), ("global_row", C.c_int64)]
+
+
+# sd_comm_callbacks (include/spindyn.h): how a sharded recursion exchanges halos and sums scalars
+EXCHANGE_START_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p)
+EXCHANGE_WAIT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int)
+
+
+class sd_comm_callbacks(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("exchange_start", EXCHANGE_START_FN), ("exchange_wait", EXCHANGE_WAIT_FN),
+                ("allreduce_sum", ALLREDUCE_FN)]
 
 
 _vp, _i, _i64, _u64, _d = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_double
@@ -111,6 +122,19 @@ PROTOTYPES = {
     "sd_apply_sharded_dev": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i64, _i, _d, _d, _d, _d, _vp, _vp, _i]),
     "sd_apply_sharded_cheb2_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _d, _d, _d, _d, _d, _d, _vp, _vp, _i]),
     "sd_kpm_step_sharded_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _d, _d, _i, _dp]),
+    "sd_comm_from_callbacks": (_i, [C.POINTER(sd_comm_callbacks), _i, _i, C.POINTER(_vp)]),
+    "sd_comm_rccl_unique_id": (_i, [_vp]),
+    "sd_comm_rccl_create": (_i, [_vp, _i, _i, _vp, C.POINTER(_vp)]),
+    "sd_comm_destroy": (None, [_vp]),
+    "sd_comm_selftest": (_i, [_vp, _vp]),
+    "sd_apply_sharded": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i64, _i]),
+    "sd_lanczos_extremal_sharded": (_i, [_vp, _vp, _vp, _i, _d, _vp, _u64, _i, _dp, _dp]),
+    "sd_energy_bounds_sharded": (_i, [_vp, _vp, _vp, _i, _u64, _dp, _dp]),
+    "sd_chebyshev_evolve_sharded": (_i, [_vp, _vp, _vp, _vp, _i64, _d, _i, _d, _d, _vp]),
+    "sd_krylov_evolve_sharded": (_i, [_vp, _vp, _vp, _i, _vp, _i64, _d, _i, _vp]),
+    "sd_kpm_moments_sharded": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _d, _d, _dp]),
+    "sd_kpm_sqw_sharded": (_i, [_vp, _vp, _vp, _i, _vp, _i64, _dp, _i, _dp, _i, _i, _d, _d, _i, _i, _u64, _dp]),
+    "sd_dot_sharded": (_i, [_vp, _vp, _i, _vp, _vp, _i64, _dp]),
     "sd_model_set_shard_mode": (_i, [_vp, _i, _i, _i]),
     "sd_model_local_tiles": (_i, [_vp, _i64p, _i64p, _ip]),
     "sd_model_shard_pack_list": (_i, [_vp, _i64p, _i64p, _ip]),

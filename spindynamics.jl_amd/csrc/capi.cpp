@@ -1,6 +1,8 @@
 // C ABI: contexts, models, operator-level entry points (include/spindyn.h).
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -25,11 +27,23 @@ int sd_pool_take(sd_ctx *ctx, size_t bytes, void **out, size_t *got) {
     ctx->pool_free.erase(ctx->pool_free.begin() + best);
     return SD_OK;
   }
+  static const bool dbg = getenv("SD_POOL_DEBUG") != nullptr;     // stderr trace of every allocation the pool could not serve
+  const auto t0 = std::chrono::steady_clock::now();
   hipError_t e = hipMalloc(out, bytes);
+  bool retried = false;
   if (e != hipSuccess) {                       // make room: drop what the pool still holds, then try once more
     (void)hipGetLastError();
     sd_pool_release(ctx);
     e = hipMalloc(out, bytes);
+    retried = true;
+  }
+  if (dbg) {
+    size_t held = 0, fr = 0, tot = 0;
+    for (auto &b : ctx->pool_free) held += b.second;
+    (void)hipMemGetInfo(&fr, &tot);
+    fprintf(stderr, "[sd pool] hipMalloc %.3f GB took %.1f ms%s; pool holds %zu blocks / %.2f GB; device free %.1f of %.1f GB\n",
+            bytes / 1e9, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(),
+            retried ? " (after dropping the pool: first attempt failed)" : "", ctx->pool_free.size(), held / 1e9, fr / 1e9, tot / 1e9);
   }
   if (e != hipSuccess) { *out = nullptr; return sd_set_err(ctx, SD_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e)); }
   *got = bytes;
@@ -134,6 +148,7 @@ const char *sd_status_string(int status) {
     case SD_EHIP: return "HIP error";
     case SD_ENODEV: return "no HIP device";
     case SD_EINTERNAL: return "internal error";
+    case SD_ECOMM: return "communication error";
     default: return "unknown status";
   }
 }
@@ -223,14 +238,19 @@ int sd_model_create(sd_ctx *ctx, int L, int nup, int n_hop, const int *hop_i, co
   if (n_hop < 0 || n_zz < 0 || n_hop > SD_MAX_BONDS || n_zz > SD_MAX_BONDS) return fail(ctx, SD_EARG, "bad bond count");
   if ((n_hop && (!hop_i || !hop_j || !hop_J)) || (n_zz && (!zz_i || !zz_j || !zz_J))) return fail(ctx, SD_EARG, "null bond list");
   for (int k = 0; k < n_hop; ++k)
-    if (hop_i[k] < 1 || hop_i[k] > L || hop_j[k] < 1 || hop_j[k] > L || hop_i[k] == hop_j[k])
+    if (hop_i[k] < 1 || hop_i[k] > L || hop_j[k] < 1 || hop_j[k] > L)
       return fail(ctx, SD_EARG, "hopping bond site out of range");
   for (int k = 0; k < n_zz; ++k)
     if (zz_i[k] < 1 || zz_i[k] > L || zz_j[k] < 1 || zz_j[k] > L) return fail(ctx, SD_EARG, "zz bond site out of range");
   sd_model *m = new (std::nothrow) sd_model();
   if (!m) return SD_ENOMEM;
   m->ctx = ctx; m->L = L; m->nup = nup;
-  m->hop_i.assign(hop_i, hop_i + n_hop); m->hop_j.assign(hop_j, hop_j + n_hop); m->hop_J.assign(hop_J, hop_J + n_hop);
+  // a hop (i, i, J) is accepted as the reference accepts it (build_model takes any pair; in apply_H! bit_i != bit_j is
+  // never true for i == j, src/Hamiltonian.jl:248-252): the term does nothing and is dropped here, the order of the rest kept
+  for (int k = 0; k < n_hop; ++k) {
+    if (hop_i[k] == hop_j[k]) continue;
+    m->hop_i.push_back(hop_i[k]); m->hop_j.push_back(hop_j[k]); m->hop_J.push_back(hop_J[k]);
+  }
   m->zz_i.assign(zz_i, zz_i + n_zz); m->zz_j.assign(zz_j, zz_j + n_zz); m->zz_J.assign(zz_J, zz_J + n_zz);
   m->field.assign(L, 0.0);
   if (field) m->field.assign(field, field + L);

@@ -289,9 +289,8 @@ __global__ __launch_bounds__(BLOCK, 4) void k_apply_tiled(sd_dev_model dm, doubl
   if (epi_has_sums(epi)) {
     double a = sums.s0, b = sums.s1;
     block_reduce2(a, b, red);
-    // one pair per tile of the launched PART (interior / boundary launches size the buffer for their own tiles only)
-    const size_t slot = (size_t)(tix - dm.part_off);
-    if (tid == 0) { partials[2 * slot] = a; partials[2 * slot + 1] = b; }
+    // one pair per tile of the plan (interior and boundary launches fill disjoint slots of one buffer sized for all tiles)
+    if (tid == 0) { partials[2 * (size_t)tix] = a; partials[2 * (size_t)tix + 1] = b; }
   }
 }
 
@@ -550,13 +549,18 @@ int sd_launch_apply(sd_ctx *ctx, const sd_model *m, int dtype, void *out, const 
   if (dtype != SD_F64 && dtype != SD_C128) return sd_set_err(ctx, SD_EARG, "dtype must be SD_F64 or SD_C128");
   const bool sums = (epi == SD_EPI_DOT || epi == SD_EPI_KPM || epi == SD_EPI_RESCALE_DOT);
   sd_dev_model dm = m->dm;
-  if (dm.n_local == 0) return SD_OK;
+  if (dm.n_local == 0) {      // a rank without rows still takes part in the reductions: its sums are zero
+    if (sums) SD_HIP(ctx, hipMemsetAsync(ea.sums_dst ? ea.sums_dst : ctx->d_scalars, 0, 2 * sizeof(double), ctx->stream));
+    return SD_OK;
+  }
   if (m->p >= 0) {
-    // part 0: every tile; 1: interior tiles only (no halo read); 2: boundary tiles only
+    // part 0: every tile; 1: interior tiles only (no halo read); 2: boundary tiles only.  A sum epilogue run in two parts
+    // (1, then 2 with the same epilogue) files its per-tile partial sums into disjoint slots of one buffer and reduces
+    // them once, after part 2: part 1 alone leaves the sums unreduced.
     int nt = dm.n_singles;
     if (part == 1) nt = dm.n_interior;
     else if (part == 2) nt = dm.n_singles - dm.n_interior;
-    if (sums) { int rc = sd_ensure_partials(ctx, 2 * (size_t)nt + 2 * SD_RED_STAGE_BLOCKS); if (rc) return rc; }
+    if (sums) { int rc = sd_ensure_partials(ctx, 2 * (size_t)dm.n_singles + 2 * SD_RED_STAGE_BLOCKS); if (rc) return rc; }
     const int max_len = m->max_tile_len;
     const size_t esz = dtype == SD_C128 ? 16 : 8;
     int rc = SD_OK;
@@ -579,7 +583,6 @@ int sd_launch_apply(sd_ctx *ctx, const sd_model *m, int dtype, void *out, const 
           if ((size_t)min_kb[cls] * 1024 > shmem) shmem = (size_t)min_kb[cls] * 1024;
         }
         dm.tile_off = m->seg_off[sg];
-        dm.part_off = m->seg_off[s0];
         if (dtype == SD_C128)
           rc = m->hop_pow2 ? launch_tiled<2, true>(ctx, dm, cnt, cls, shmem, (double *)out, (const double *)psi, epi, ea, seg_max)
                            : launch_tiled<2, false>(ctx, dm, cnt, cls, shmem, (double *)out, (const double *)psi, epi, ea, seg_max);
@@ -589,8 +592,8 @@ int sd_launch_apply(sd_ctx *ctx, const sd_model *m, int dtype, void *out, const 
       }
       if (rc) return rc;
     }
-    if (sums) {
-      int rc2 = sd_reduce_pairs(ctx, (int64_t)nt, ea.sums_dst);
+    if (sums && part != 1) {
+      int rc2 = sd_reduce_pairs(ctx, (int64_t)dm.n_singles, ea.sums_dst);
       if (rc2) return rc2;
     }
   } else if (m->full_ls > 0) {

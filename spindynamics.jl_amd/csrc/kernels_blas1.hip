@@ -14,8 +14,9 @@ namespace {
 constexpr int RED_BLOCKS = 2048;
 constexpr int BS = 256;
 
-// conj(x).y for complex (nc=2) or x.y for real (nc=1); n2 = number of double2 elements when vectorised
-template <int NC>
+// conj(x).y for complex (nc=2) or x.y for real (nc=1); n2 = number of double2 elements when vectorised.
+// CONJ = false (complex only): the plain product sum x_i*y_i -- LanczosSqw.jl:59 forms dot(conj(psi), H psi)
+template <int NC, bool CONJ = true>
 __global__ __launch_bounds__(BS) void k_dot(const double *__restrict__ x, const double *__restrict__ y, int64_t N,
                                             double *__restrict__ partials) {
   __shared__ double red[32];
@@ -25,8 +26,8 @@ __global__ __launch_bounds__(BS) void k_dot(const double *__restrict__ x, const 
     const double2 *x2 = (const double2 *)x, *y2 = (const double2 *)y;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += stride) {
       double2 u = x2[i], v = y2[i];
-      a += u.x * v.x + u.y * v.y;
-      b += u.x * v.y - u.y * v.x;
+      if (CONJ) { a += u.x * v.x + u.y * v.y; b += u.x * v.y - u.y * v.x; }
+      else { a += u.x * v.x - u.y * v.y; b += u.x * v.y + u.y * v.x; }
     }
   } else {
     const int64_t n2 = (((uintptr_t)x | (uintptr_t)y) & 15) ? 0 : N / 2;
@@ -294,6 +295,15 @@ int sd_k_dot(sd_ctx *ctx, int nc, const double *x, const double *y, int64_t N, i
   int nb = (int)std::min<int64_t>(RED_BLOCKS, std::max<int64_t>(1, (N + BS - 1) / BS));
   if (nc == 2) hipLaunchKernelGGL(k_dot<2>, dim3(nb), dim3(BS), 0, ctx->stream, x, y, N, ctx->d_partials);
   else hipLaunchKernelGGL(k_dot<1>, dim3(nb), dim3(BS), 0, ctx->stream, x, y, N, ctx->d_partials);
+  hipLaunchKernelGGL(k_reduce_to, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_partials, nb, ctx->d_scalars + slot);
+  SD_HIP(ctx, hipGetLastError());
+  return SD_OK;
+}
+
+int sd_k_dotu(sd_ctx *ctx, const double *x, const double *y, int64_t N, int slot) {   // sum x_i*y_i (complex, no conjugation)
+  int rc = sd_ensure_partials(ctx, 2 * RED_BLOCKS); if (rc) return rc;
+  int nb = (int)std::min<int64_t>(RED_BLOCKS, std::max<int64_t>(1, (N + BS - 1) / BS));
+  hipLaunchKernelGGL((k_dot<2, false>), dim3(nb), dim3(BS), 0, ctx->stream, x, y, N, ctx->d_partials);
   hipLaunchKernelGGL(k_reduce_to, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_partials, nb, ctx->d_scalars + slot);
   SD_HIP(ctx, hipGetLastError());
   return SD_OK;

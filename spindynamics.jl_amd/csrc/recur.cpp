@@ -21,6 +21,8 @@
 
 namespace {
 
+#define RC(x) do { int rc__ = (x); if (rc__) return rc__; } while (0)
+
 struct DBuf {   // device work vector, taken from / returned to the context's pool
   double *p = nullptr;
   sd_ctx *owner = nullptr;
@@ -43,8 +45,6 @@ struct DBuf {   // device work vector, taken from / returned to the context's po
   }
 };
 
-#define RC(x) do { int rc__ = (x); if (rc__) return rc__; } while (0)
-
 int h2d(sd_ctx *ctx, double *d, const void *h, int64_t doubles) {
   SD_HIP(ctx, hipMemcpyAsync(d, h, sizeof(double) * (size_t)doubles, hipMemcpyHostToDevice, ctx->stream));
   SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -60,17 +60,55 @@ int d2d(sd_ctx *ctx, double *dst, const double *src, int64_t doubles) {
   return SD_OK;
 }
 
-int check_unsharded(sd_ctx *ctx, const sd_model *m) {
-  if (!ctx) return SD_EARG;
-  if (!m || !m->dev_ready) return sd_set_err(ctx, SD_EARG, "model has no device tables");
-  if (m->nranks != 1) return sd_set_err(ctx, SD_EARG, "recursion-level entry points run on an unsharded model");
-  SD_HIP(ctx, hipSetDevice(ctx->device));
-  return SD_OK;
-}
+// What a recursion needs from "the operator": the apply on this rank's rows (halo exchange included) and the sum of device
+// scalars over the ranks.  Unsharded (comm == nullptr, nranks == 1) both reduce to the plain launch / nothing, so the same
+// loops serve the single-GPU and the sharded entry points.
+struct Op {
+  sd_ctx *ctx = nullptr;
+  const sd_model *m = nullptr;
+  sd_comm *comm = nullptr;
+  int64_t n = 0;             // rows of this rank (== N unsharded)
+  DBuf halo, send;           // imported partner tiles / tiles packed for the peers (sharded plans; ComplexF64-sized)
+  bool overlap = true;       // interior tiles run while the exchange is in flight
 
-double norm_dev(sd_ctx *ctx, const double *x, int64_t n, int *rc) {
+  int init(sd_ctx *c, const sd_model *mm, sd_comm *cm) {
+    if (!c) return SD_EARG;
+    ctx = c; m = mm; comm = cm;
+    if (!m || !m->dev_ready) return sd_set_err(ctx, SD_EARG, "model has no device tables");
+    if (m->nranks != 1 && !comm) return sd_set_err(ctx, SD_EARG, "a sharded model needs a communicator (the unsharded entry points take an unsharded model)");
+    if (comm && sd_comm_nranks(comm) != m->nranks) return sd_set_err(ctx, SD_EARG, "communicator size does not match the model's shard count");
+    SD_HIP(ctx, hipSetDevice(ctx->device));
+    n = m->n_local;
+    if (m->nranks > 1) {
+      RC(halo.alloc(ctx, 2 * std::max<int64_t>(m->n_halo, 1)));
+      if (m->shard_mode == 1) RC(send.alloc(ctx, 2 * std::max<int64_t>(m->n_send, 1)));
+    }
+    return SD_OK;
+  }
+  // out = epilogue(H psi) on the owned rows.  Sharded: pack (cell mode), post the exchange, interior tiles, wait, boundary tiles.
+  int apply(int dtype, double *out, const double *psi, int epi, sd_epi_args ea) {
+    if (m->nranks == 1) return sd_launch_apply(ctx, m, dtype, out, psi, epi, ea, 0);
+    ea.halo = halo.p;
+    const void *src = psi;
+    if (m->shard_mode == 1) { RC(sd_launch_pack(ctx, m, dtype, psi, send.p)); src = send.p; }
+    RC(sd_comm_exchange_start(ctx, comm, m, dtype, src, halo.p));
+    if (overlap && m->n_interior > 0 && n > 0) {
+      RC(sd_launch_apply(ctx, m, dtype, out, psi, epi, ea, 1));
+      RC(sd_comm_exchange_wait(ctx, comm, m));
+      return sd_launch_apply(ctx, m, dtype, out, psi, epi, ea, 2);
+    }
+    RC(sd_comm_exchange_wait(ctx, comm, m));
+    return sd_launch_apply(ctx, m, dtype, out, psi, epi, ea, 0);
+  }
+  // device scalars <- their sum over the ranks (in place, ordered on the context's stream)
+  int reduce(double *dev, int count) { return sd_comm_allreduce_dev(ctx, comm, dev, count); }
+};
+
+double norm_dev(Op &op, const double *x, int64_t n, int *rc) {
   double v = 0.0;
+  sd_ctx *ctx = op.ctx;
   *rc = sd_k_nrm2sq(ctx, x, n, 2);
+  if (!*rc) *rc = op.reduce(ctx->d_scalars + 2, 1);
   if (!*rc) *rc = sd_read_scalars(ctx, 2, 1, &v);
   return std::sqrt(v);
 }
@@ -89,17 +127,17 @@ int peek_breakdown(sd_ctx *ctx, const double *d_be, int count, double tol, std::
   return SD_OK;
 }
 
-// lanczos_extremal on device vectors; d_start (2N doubles, un-normalised) is consumed
-int extremal_dev(sd_ctx *ctx, const sd_model *m, int lanc_m, double tol, double *v_prev, int negate,
-                 double *emin, double *emax) {
-  const int64_t N = m->N;
-  const int mm = (int)std::min<int64_t>(lanc_m, N);
+// lanczos_extremal on device vectors; v_prev (2n doubles, un-normalised start) is consumed
+int extremal_dev(Op &op, int lanc_m, double tol, double *v_prev, int negate, double *emin, double *emax) {
+  sd_ctx *ctx = op.ctx;
+  const int64_t N = op.n;
+  const int mm = (int)std::min<int64_t>(lanc_m, op.m->N);
   if (mm < 1) return sd_set_err(ctx, SD_EARG, "lanc_m must be >= 1");
   DBuf w, vc;
   RC(w.alloc(ctx, 2 * N)); RC(vc.alloc(ctx, 2 * N));
   double *v_curr = vc.p;
   int rc = 0;
-  double nrm = norm_dev(ctx, v_prev, 2 * N, &rc); RC(rc);
+  double nrm = norm_dev(op, v_prev, 2 * N, &rc); RC(rc);
   RC(sd_k_scale_div(ctx, v_prev, v_prev, 2 * N, nrm));                     // :40
   // the loop is queued without host round trips (alpha_j, beta_j stay on the device, see tridiag_dev); the break on
   // beta_j < tol (:66-70) is applied to the values read back at the end
@@ -109,11 +147,13 @@ int extremal_dev(sd_ctx *ctx, const sd_model *m, int lanc_m, double tol, double 
   sd_epi_args ea; ea.negate = negate;
   std::vector<double> peek;
   for (int j = 1; j <= mm; ++j) {
-    RC(sd_launch_apply(ctx, m, SD_C128, w.p, v_prev, SD_EPI_DOT, ea));     // :51 + :55 fused -> d_scalars[0]
+    RC(op.apply(SD_C128, w.p, v_prev, SD_EPI_DOT, ea));                    // :51 + :55 fused -> d_scalars[0]
+    RC(op.reduce(ctx->d_scalars + 0, 2));
     RC(sd_k_sub_axpby_nrm_devs(ctx, w.p, v_prev, j == 1 ? nullptr : v_curr, 2 * N, ctx->d_scalars + 0,
                                j == 1 ? nullptr : d_be + (j - 2), d_al + (j - 1), 2));
     if (j < mm) {
       std::swap(v_curr, v_prev);
+      RC(op.reduce(ctx->d_scalars + 2, 1));
       RC(sd_k_scale_div_devs(ctx, v_prev, w.p, 2 * N, ctx->d_scalars + 2, d_be + (j - 1)));   // :65, :71
     }
     if (j % SD_BREAK_PEEK == 0 && j < mm) {
@@ -138,14 +178,18 @@ int extremal_dev(sd_ctx *ctx, const sd_model *m, int lanc_m, double tol, double 
   return SD_OK;
 }
 
-int start_vector(sd_ctx *ctx, double *d, const void *host, int64_t doubles, uint64_t seed) {
-  if (host) return h2d(ctx, d, host, doubles);
-  return sd_k_fill_randn(ctx, d, doubles, seed, 0);
+// start vector of this rank's rows: the caller's (host pointer, unsharded calls; device pointer, sharded calls) or the
+// counter-based N(0,1) vector keyed by the GLOBAL element index -- the same state for every sharding
+int start_vector_op(Op &op, double *d, const void *given, bool given_on_dev, int64_t doubles, uint64_t seed) {
+  if (given) return given_on_dev ? d2d(op.ctx, d, (const double *)given, doubles) : h2d(op.ctx, d, given, doubles);
+  if (op.m->nranks > 1) return sd_launch_fill_randn_local(op.ctx, op.m, SD_C128, d, seed);
+  return sd_k_fill_randn(op.ctx, d, doubles, seed, 0);
 }
 
-int moments_dev(sd_ctx *ctx, const sd_model *m, const double *phi, int M, double a, double b, double *mu) {
-  // compute_chebyshev_moments  src/KPM_Sqw.jl:95-128  (phi: device, c128, normalised by the caller)
-  const int64_t N = m->N;
+int moments_dev(Op &op, const double *phi, int M, double a, double b, double *mu) {
+  // compute_chebyshev_moments  src/KPM_Sqw.jl:95-128  (phi: device, c128, this rank's rows, normalised by the caller)
+  sd_ctx *ctx = op.ctx;
+  const int64_t N = op.n;
   if (M < 2) return sd_set_err(ctx, SD_EARG, "kpm_m must be >= 2");
   DBuf b0, b1, b2;
   RC(b0.alloc(ctx, 2 * N)); RC(b1.alloc(ctx, 2 * N)); RC(b2.alloc(ctx, 2 * N));
@@ -153,16 +197,19 @@ int moments_dev(sd_ctx *ctx, const sd_model *m, const double *phi, int M, double
   for (int doubling = ctx->kpm_doubling ? 1 : 0; doubling >= 0; --doubling) {
     double *v_prev = b0.p, *v_curr = b1.p, *v_next = b2.p;
     RC(d2d(ctx, v_prev, phi, 2 * N));
-    RC(sd_k_dot(ctx, 2, phi, v_prev, N, 4)); RC(sd_read_scalars(ctx, 4, 2, s)); mu[0] = s[0];      // :103
+    RC(sd_k_dot(ctx, 2, phi, v_prev, N, 4)); RC(op.reduce(ctx->d_scalars + 4, 2));
+    RC(sd_read_scalars(ctx, 4, 2, s)); mu[0] = s[0];                                                // :103
     sd_epi_args ea; ea.a = a; ea.b = b;
     if (!doubling) {
       // the reference's recursion: one moment <phi|T_k phi> per apply
       ea.phi = phi;
-      RC(sd_launch_apply(ctx, m, SD_C128, v_curr, v_prev, SD_EPI_RESCALE_DOT, ea));                 // :106-107
+      RC(op.apply(SD_C128, v_curr, v_prev, SD_EPI_RESCALE_DOT, ea));                                // :106-107
+      RC(op.reduce(ctx->d_scalars + 0, 2));
       RC(sd_read_scalars(ctx, 0, 2, s)); mu[1] = s[0];
       for (int k = 2; k <= M - 1; ++k) {
         ea.prev = v_prev;
-        RC(sd_launch_apply(ctx, m, SD_C128, v_next, v_curr, SD_EPI_KPM, ea));                       // :111-117 fused
+        RC(op.apply(SD_C128, v_next, v_curr, SD_EPI_KPM, ea));                                      // :111-117 fused
+        RC(op.reduce(ctx->d_scalars + 0, 2));
         RC(sd_read_scalars(ctx, 0, 2, s));
         mu[k] = s[0];
         const double nv = std::sqrt(s[1]);
@@ -181,10 +228,12 @@ int moments_dev(sd_ctx *ctx, const sd_model *m, const double *phi, int M, double
     const int nsteps = M / 2;                                   // applies: v_1 .. v_nsteps
     DBuf sm; RC(sm.alloc(ctx, 2 * (int64_t)nsteps + 2));
     ea.sums_dst = sm.p;
-    RC(sd_launch_apply(ctx, m, SD_C128, v_curr, v_prev, SD_EPI_RESCALE_DOT, ea));
+    RC(op.apply(SD_C128, v_curr, v_prev, SD_EPI_RESCALE_DOT, ea));
+    RC(op.reduce(sm.p, 2));
     for (int n = 1; n < nsteps; ++n) {
       ea.prev = v_prev; ea.sums_dst = sm.p + 2 * n;
-      RC(sd_launch_apply(ctx, m, SD_C128, v_next, v_curr, SD_EPI_KPM, ea));                         // v_{n+1}
+      RC(op.apply(SD_C128, v_next, v_curr, SD_EPI_KPM, ea));                                        // v_{n+1}
+      RC(op.reduce(sm.p + 2 * n, 2));
       double *t = v_prev; v_prev = v_curr; v_curr = v_next; v_next = t;
     }
     std::vector<double> hs(2 * (size_t)nsteps);
@@ -203,15 +252,16 @@ int moments_dev(sd_ctx *ctx, const sd_model *m, const double *phi, int M, double
   return SD_OK;
 }
 
-int tridiag_dev(sd_ctx *ctx, const sd_model *m, double *vcur /* normalised start, consumed */, int lanc_m, double tol,
+int tridiag_dev(Op &op, double *vcur /* normalised start, consumed */, int lanc_m, double tol,
                 double *alpha, double *beta, int *m_eff_out) {
   // lanczos_tridiag  src/Lanczos.jl:196-246 with two live vectors (the reference keeps all m).
   // No host round trip inside the loop: alpha_j and beta_j stay on the device (the update and normalisation passes read
   // them there and file them into d_al / d_be), so the whole recursion is queued at once and read back once.  The
   // reference's break on beta_j < tol (:228-231) is applied afterwards: the steps before it are unaffected by what was
   // queued behind them, the rest is discarded.
-  const int64_t n = m->N;
-  const int mm = (int)std::min<int64_t>(lanc_m, n);
+  sd_ctx *ctx = op.ctx;
+  const int64_t n = op.n;
+  const int mm = (int)std::min<int64_t>(lanc_m, op.m->N);
   DBuf wb, vp, ab;
   RC(wb.alloc(ctx, 2 * n)); RC(vp.alloc(ctx, 2 * n)); RC(ab.alloc(ctx, 2 * (int64_t)mm));
   double *w = wb.p, *vprev = vp.p, *d_al = ab.p, *d_be = ab.p + mm;
@@ -219,10 +269,12 @@ int tridiag_dev(sd_ctx *ctx, const sd_model *m, double *vcur /* normalised start
   sd_epi_args ea;
   std::vector<double> peek;
   for (int j = 1; j <= mm - 1; ++j) {
-    RC(sd_launch_apply(ctx, m, SD_C128, w, vcur, SD_EPI_DOT, ea));                                 // :218-219 -> d_scalars[0]
+    RC(op.apply(SD_C128, w, vcur, SD_EPI_DOT, ea));                                                // :218-219 -> d_scalars[0]
+    RC(op.reduce(ctx->d_scalars + 0, 2));
     RC(sd_k_sub2_nrm_devs(ctx, w, vcur, j > 1 ? vprev : nullptr, 2 * n, ctx->d_scalars + 0, j > 1 ? d_be + (j - 2) : nullptr,
                           d_al + (j - 1), 2));                                                     // :222-224, |w|^2 -> [2]
     std::swap(vprev, vcur);
+    RC(op.reduce(ctx->d_scalars + 2, 1));
     RC(sd_k_scale_div_devs(ctx, vcur, w, 2 * n, ctx->d_scalars + 2, d_be + (j - 1)));              // :227, :233
     if (j % SD_BREAK_PEEK == 0 && j < mm - 1) {       // bound the work queued behind a breakdown: look at the betas so far
       bool broke = false;
@@ -230,7 +282,8 @@ int tridiag_dev(sd_ctx *ctx, const sd_model *m, double *vcur /* normalised start
       if (broke) break;
     }
   }
-  RC(sd_launch_apply(ctx, m, SD_C128, w, vcur, SD_EPI_DOT, ea));                                   // :237-239
+  RC(op.apply(SD_C128, w, vcur, SD_EPI_DOT, ea));                                                  // :237-239
+  RC(op.reduce(ctx->d_scalars + 0, 2));
   SD_HIP(ctx, hipMemcpyAsync(d_al + (mm - 1), ctx->d_scalars + 0, sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
   std::vector<double> host(2 * (size_t)mm);
   SD_HIP(ctx, hipMemcpyAsync(host.data(), ab.p, sizeof(double) * 2 * (size_t)mm, hipMemcpyDeviceToHost, ctx->stream));
@@ -397,47 +450,98 @@ extern "C" int sd_spectral_from_tridiagonal(const double *alpha, const double *b
 // recursion-level C ABI
 // --------------------------------------------------------------------------
 
-extern "C" int sd_lanczos_extremal(sd_ctx *ctx, const sd_model *m, int lanc_m, double tol, const void *psi0,
-                                   uint64_t seed, int negate, double *emin, double *emax) {
-  RC(check_unsharded(ctx, m));
-  if (!emin || !emax) return sd_set_err(ctx, SD_EARG, "null output");
-  DBuf v; RC(v.alloc(ctx, 2 * m->N));
-  RC(start_vector(ctx, v.p, psi0, 2 * m->N, seed));
-  return extremal_dev(ctx, m, lanc_m, tol, v.p, negate, emin, emax);
-}
-
-extern "C" int sd_energy_bounds(sd_ctx *ctx, const sd_model *m, int lanc_m, const void *psi0_a, const void *psi0_b,
-                                uint64_t seed, double *Emin, double *Emax) {
-  RC(check_unsharded(ctx, m));
-  if (!Emin || !Emax) return sd_set_err(ctx, SD_EARG, "null output");
+// Every entry point exists in two forms sharing one core: the unsharded form (host vectors in / out, comm == nullptr) and
+// the sharded form (this rank's rows as device vectors, a communicator).
+static int energy_bounds_core(Op &op, int lanc_m, const void *psi0_a, const void *psi0_b, bool on_dev, uint64_t seed,
+                              double *Emin, double *Emax) {
+  sd_ctx *ctx = op.ctx;
   double lo, hi;
   {
-    DBuf v; RC(v.alloc(ctx, 2 * m->N));
-    RC(start_vector(ctx, v.p, psi0_a, 2 * m->N, seed));
-    RC(extremal_dev(ctx, m, lanc_m, 1e-12, v.p, 0, &lo, &hi));          // src/Lanczos.jl:258
+    DBuf v; RC(v.alloc(ctx, 2 * op.n));
+    RC(start_vector_op(op, v.p, psi0_a, on_dev, 2 * op.n, seed));
+    RC(extremal_dev(op, lanc_m, 1e-12, v.p, 0, &lo, &hi));              // src/Lanczos.jl:258
     *Emax = hi;
   }
   {
-    DBuf v; RC(v.alloc(ctx, 2 * m->N));
-    RC(start_vector(ctx, v.p, psi0_b, 2 * m->N, seed + 0x9E3779B97F4A7C15ULL));
-    RC(extremal_dev(ctx, m, lanc_m, 1e-12, v.p, 1, &lo, &hi));          // :261-267
+    DBuf v; RC(v.alloc(ctx, 2 * op.n));
+    RC(start_vector_op(op, v.p, psi0_b, on_dev, 2 * op.n, seed + 0x9E3779B97F4A7C15ULL));
+    RC(extremal_dev(op, lanc_m, 1e-12, v.p, 1, &lo, &hi));              // :261-267
     *Emin = -hi;
   }
   return SD_OK;
 }
 
+extern "C" int sd_lanczos_extremal(sd_ctx *ctx, const sd_model *m, int lanc_m, double tol, const void *psi0,
+                                   uint64_t seed, int negate, double *emin, double *emax) {
+  Op op; RC(op.init(ctx, m, nullptr));
+  if (!emin || !emax) return sd_set_err(ctx, SD_EARG, "null output");
+  DBuf v; RC(v.alloc(ctx, 2 * op.n));
+  RC(start_vector_op(op, v.p, psi0, false, 2 * op.n, seed));
+  return extremal_dev(op, lanc_m, tol, v.p, negate, emin, emax);
+}
+
+extern "C" int sd_lanczos_extremal_sharded(sd_ctx *ctx, const sd_model *m, sd_comm *comm, int lanc_m, double tol,
+                                           const void *psi0_dev, uint64_t seed, int negate, double *emin, double *emax) {
+  Op op; RC(op.init(ctx, m, comm));
+  if (!emin || !emax) return sd_set_err(ctx, SD_EARG, "null output");
+  DBuf v; RC(v.alloc(ctx, 2 * op.n));
+  RC(start_vector_op(op, v.p, psi0_dev, true, 2 * op.n, seed));
+  return extremal_dev(op, lanc_m, tol, v.p, negate, emin, emax);
+}
+
+extern "C" int sd_energy_bounds(sd_ctx *ctx, const sd_model *m, int lanc_m, const void *psi0_a, const void *psi0_b,
+                                uint64_t seed, double *Emin, double *Emax) {
+  Op op; RC(op.init(ctx, m, nullptr));
+  if (!Emin || !Emax) return sd_set_err(ctx, SD_EARG, "null output");
+  return energy_bounds_core(op, lanc_m, psi0_a, psi0_b, false, seed, Emin, Emax);
+}
+
+extern "C" int sd_energy_bounds_sharded(sd_ctx *ctx, const sd_model *m, sd_comm *comm, int lanc_m, uint64_t seed,
+                                        double *Emin, double *Emax) {
+  Op op; RC(op.init(ctx, m, comm));
+  if (!Emin || !Emax) return sd_set_err(ctx, SD_EARG, "null output");
+  return energy_bounds_core(op, lanc_m, nullptr, nullptr, true, seed, Emin, Emax);
+}
+
+extern "C" int sd_apply_sharded(sd_ctx *ctx, const sd_model *m, sd_comm *comm, int dtype, void *out_dev, const void *psi_dev,
+                                int64_t n_local, int overlap) {
+  if (!ctx) return SD_EARG;
+  if (!m || !out_dev || !psi_dev) return sd_set_err(ctx, SD_EARG, "null argument");
+  if (dtype != SD_F64 && dtype != SD_C128) return sd_set_err(ctx, SD_EARG, "dtype must be SD_F64 or SD_C128");
+  if (out_dev == psi_dev) return sd_set_err(ctx, SD_EARG, "out must not alias psi");
+  Op op; RC(op.init(ctx, m, comm));
+  if (n_local != op.n) return sd_set_err(ctx, SD_EDIM, "vector length does not match the local basis dimension");
+  op.overlap = overlap != 0;
+  sd_epi_args ea;
+  RC(op.apply(dtype, (double *)out_dev, (const double *)psi_dev, SD_EPI_PLAIN, ea));
+  SD_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the halo / send buffers go back to the pool
+  return SD_OK;
+}
+
+extern "C" int sd_dot_sharded(sd_ctx *ctx, sd_comm *comm, int dtype, const void *x, const void *y, int64_t n_local,
+                              double *out2) {
+  if (!ctx) return SD_EARG;
+  if (!x || !y || !out2 || n_local < 0) return sd_set_err(ctx, SD_EARG, "bad argument");
+  if (dtype != SD_F64 && dtype != SD_C128) return sd_set_err(ctx, SD_EARG, "bad dtype");
+  SD_HIP(ctx, hipSetDevice(ctx->device));
+  RC(sd_k_dot(ctx, dtype == SD_C128 ? 2 : 1, (const double *)x, (const double *)y, n_local, 4));
+  RC(sd_comm_allreduce_dev(ctx, comm, ctx->d_scalars + 4, 2));
+  return sd_read_scalars(ctx, 4, 2, out2);
+}
+
 extern "C" int sd_lanczos_groundstate(sd_ctx *ctx, const sd_model *m, int lanc_m, double tol, double orth_tol,
                                       const double *psi0, uint64_t seed, double *E0, double *psi_gs, int *m_actual_out) {
-  RC(check_unsharded(ctx, m));
+  Op op; RC(op.init(ctx, m, nullptr));
   if (!E0 || !psi_gs) return sd_set_err(ctx, SD_EARG, "null output");
   const int64_t N = m->N;
   const int mm = (int)std::min<int64_t>(lanc_m, N);
   if (mm < 1) return sd_set_err(ctx, SD_EARG, "lanc_m must be >= 1");
   DBuf V, w, tmp;
   RC(V.alloc(ctx, N * (int64_t)mm)); RC(w.alloc(ctx, N)); RC(tmp.alloc(ctx, N));
-  RC(start_vector(ctx, V.p, psi0, N, seed));
+  if (psi0) RC(h2d(ctx, V.p, psi0, N));
+  else RC(sd_k_fill_randn(ctx, V.p, N, seed, 0));
   int rc = 0;
-  double nrm = norm_dev(ctx, V.p, N, &rc); RC(rc);
+  double nrm = norm_dev(op, V.p, N, &rc); RC(rc);
   RC(sd_k_scale_div(ctx, V.p, V.p, N, nrm));                                             // :100,105
   std::vector<double> alpha(mm, 0.0), beta(mm, 0.0);
   int m_actual = mm;
@@ -453,7 +557,7 @@ extern "C" int sd_lanczos_groundstate(sd_ctx *ctx, const sd_model *m, int lanc_m
     RC(sd_k_sub2(ctx, w.p, vj, j == 1 ? nullptr : V.p + N * (int64_t)(j - 2), N, alpha[j - 1],
                  j == 1 ? 0.0 : beta[j - 2]));                                           // :127-129
     if (j < mm) {
-      beta[j - 1] = norm_dev(ctx, w.p, N, &rc); RC(rc);                                  // :133
+      beta[j - 1] = norm_dev(op, w.p, N, &rc); RC(rc);                                   // :133
       if (beta[j - 1] < tol) { m_actual = j; break; }                                    // :136-139
       // :142-153: for k = 1..j test |dot(V[:,k], w/beta)| > orth_tol and correct w when it fires (then w/beta changes).
       // The tests between two corrections all use the same w/beta, so they are taken in one pass (sd_k_mdot) and the
@@ -469,7 +573,7 @@ extern "C" int sd_lanczos_groundstate(sd_ctx *ctx, const sd_model *m, int lanc_m
         double *vk = V.p + N * (int64_t)(hit - 1);
         RC(sd_k_dot(ctx, 1, vk, w.p, N, 4)); RC(sd_read_scalars(ctx, 4, 1, s));
         RC(sd_k_sub2(ctx, w.p, vk, nullptr, N, s[0], 0.0));
-        beta[j - 1] = norm_dev(ctx, w.p, N, &rc); RC(rc);
+        beta[j - 1] = norm_dev(op, w.p, N, &rc); RC(rc);
         if (beta[j - 1] < tol) { m_actual = j; break; }                                 // inner break only (:150)
         k = hit + 1;
       }
@@ -481,7 +585,7 @@ extern "C" int sd_lanczos_groundstate(sd_ctx *ctx, const sd_model *m, int lanc_m
     return sd_set_err(ctx, SD_EINTERNAL, "tridiagonal eigen-solver did not converge");
   *E0 = ev[0];                                                                           // :167
   RC(sd_k_gemv_cols(ctx, w.p, V.p, N, m_actual, Z.data()));                              // :170 (first eigenvector = column 0)
-  nrm = norm_dev(ctx, w.p, N, &rc); RC(rc);
+  nrm = norm_dev(op, w.p, N, &rc); RC(rc);
   RC(sd_k_scale_div(ctx, w.p, w.p, N, nrm));                                             // :171
   RC(d2h(ctx, psi_gs, w.p, N));
   if (m_actual_out) *m_actual_out = m_actual;
@@ -490,24 +594,23 @@ extern "C" int sd_lanczos_groundstate(sd_ctx *ctx, const sd_model *m, int lanc_m
 
 extern "C" int sd_lanczos_tridiag(sd_ctx *ctx, const sd_model *m, const void *v, int64_t n, int lanc_m, double tol,
                                   double *alpha, double *beta, int *m_eff, double *norm_v) {
-  RC(check_unsharded(ctx, m));
+  Op op; RC(op.init(ctx, m, nullptr));
   if (n != m->N) return sd_set_err(ctx, SD_EDIM, "vector length does not match the basis dimension");
   if (!v || !alpha || !beta || !m_eff || !norm_v) return sd_set_err(ctx, SD_EARG, "null argument");
   if (lanc_m < 1) return sd_set_err(ctx, SD_EARG, "lanc_m must be >= 1");
   DBuf vc; RC(vc.alloc(ctx, 2 * n));
   RC(h2d(ctx, vc.p, v, 2 * n));
   int rc = 0;
-  const double normv = norm_dev(ctx, vc.p, 2 * n, &rc); RC(rc);
+  const double normv = norm_dev(op, vc.p, 2 * n, &rc); RC(rc);
   if (normv == 0) return sd_set_err(ctx, SD_EZERO, "starting vector has zero norm");     // :210-212
   RC(sd_k_scale_div(ctx, vc.p, vc.p, 2 * n, normv));
   *norm_v = normv;
-  return tridiag_dev(ctx, m, vc.p, lanc_m, tol, alpha, beta, m_eff);
+  return tridiag_dev(op, vc.p, lanc_m, tol, alpha, beta, m_eff);
 }
 
 // krylov_time_evolve; on_dev: psi0 / psit are device vectors (psit ComplexF64; may alias a ComplexF64 psi0)
-static int krylov_evolve_core(sd_ctx *ctx, const sd_model *m, int dtype, const void *psi0, int64_t n, double dt, int kry_m,
-                              void *psit, bool on_dev) {
-  RC(check_unsharded(ctx, m));
+static int krylov_evolve_core(Op &op, int dtype, const void *psi0, int64_t n, double dt, int kry_m, void *psit, bool on_dev) {
+  sd_ctx *ctx = op.ctx;
   if (!psi0 || !psit) return sd_set_err(ctx, SD_EARG, "null vector");
   auto emit = [&](const double *src) -> int {          // result to the caller
     if (!on_dev) return d2h(ctx, psit, src, 2 * n);
@@ -515,7 +618,7 @@ static int krylov_evolve_core(sd_ctx *ctx, const sd_model *m, int dtype, const v
     SD_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the work vectors go back to the pool: nothing may still use them
     return SD_OK;
   };
-  if (n != m->N) return sd_set_err(ctx, SD_EDIM, "vector length does not match the basis dimension");
+  if (n != op.n) return sd_set_err(ctx, SD_EDIM, "vector length does not match the (local) basis dimension");
   if (dtype != SD_F64 && dtype != SD_C128) return sd_set_err(ctx, SD_EARG, "bad dtype");
   if (kry_m < 1) return sd_set_err(ctx, SD_EARG, "kry_m must be >= 1");
   const int nc = dtype == SD_C128 ? 2 : 1;
@@ -526,7 +629,7 @@ static int krylov_evolve_core(sd_ctx *ctx, const sd_model *m, int dtype, const v
   const double *inp = (const double *)psi0;
   if (!on_dev) { RC(in.alloc(ctx, nc * n)); RC(h2d(ctx, in.p, psi0, nc * n)); inp = in.p; }
   int rc = 0;
-  const double norm0 = norm_dev(ctx, inp, nc * n, &rc); RC(rc);
+  const double norm0 = norm_dev(op, inp, nc * n, &rc); RC(rc);
   RC(V[0].alloc(ctx, 2 * n));
   RC(sd_k_promote(ctx, V[0].p, inp, nc, n));
   if (norm0 == 0) return emit(V[0].p);                                                    // :145-147
@@ -538,11 +641,13 @@ static int krylov_evolve_core(sd_ctx *ctx, const sd_model *m, int dtype, const v
   SD_HIP(ctx, hipMemsetAsync(ab.p, 0, sizeof(double) * 3 * (size_t)kry_m, ctx->stream));
   sd_epi_args ea;
   for (int j = 1; j <= kry_m; ++j) {
-    RC(sd_launch_apply(ctx, m, SD_C128, w.p, V[j - 1].p, SD_EPI_DOT, ea));                // :153,155 -> d_scalars[0..1]
+    RC(op.apply(SD_C128, w.p, V[j - 1].p, SD_EPI_DOT, ea));                               // :153,155 -> d_scalars[0..1]
+    RC(op.reduce(ctx->d_scalars + 0, 2));
     RC(sd_k_krylov_update_nrm_devs(ctx, w.p, V[j - 1].p, j > 1 ? V[j - 2].p : nullptr, n, ctx->d_scalars + 0,
                                    j > 1 ? d_be + (j - 2) : nullptr, d_al + 2 * (j - 1), 2));   // :156-159 + :161 in one pass
     if (j < kry_m) {
       RC(V[j].alloc(ctx, 2 * n));
+      RC(op.reduce(ctx->d_scalars + 2, 1));
       RC(sd_k_scale_div_devs(ctx, V[j].p, w.p, 2 * n, ctx->d_scalars + 2, d_be + (j - 1)));   // :161, :169
     }
   }
@@ -576,28 +681,36 @@ static int krylov_evolve_core(sd_ctx *ctx, const sd_model *m, int dtype, const v
     for (int k = 0; k < m_eff; ++k) cols[k] = V[k].p;
     RC(sd_k_ccombine(ctx, w.p, cols.data(), n, m_eff, yr.data(), yi.data()));
   }
-  const double nn = norm_dev(ctx, w.p, 2 * n, &rc); RC(rc);
+  const double nn = norm_dev(op, w.p, 2 * n, &rc); RC(rc);
   RC(sd_k_scale_div(ctx, w.p, w.p, 2 * n, nn));                                           // :190
   return emit(w.p);
 }
 
 extern "C" int sd_krylov_evolve(sd_ctx *ctx, const sd_model *m, int dtype, const void *psi0, int64_t n, double dt,
                                 int kry_m, void *psit) {
-  return krylov_evolve_core(ctx, m, dtype, psi0, n, dt, kry_m, psit, false);
+  Op op; RC(op.init(ctx, m, nullptr));
+  return krylov_evolve_core(op, dtype, psi0, n, dt, kry_m, psit, false);
 }
 
 extern "C" int sd_krylov_evolve_dev(sd_ctx *ctx, const sd_model *m, int dtype, const void *psi0_dev, int64_t n, double dt,
                                     int kry_m, void *psit_dev) {
-  return krylov_evolve_core(ctx, m, dtype, psi0_dev, n, dt, kry_m, psit_dev, true);
+  Op op; RC(op.init(ctx, m, nullptr));
+  return krylov_evolve_core(op, dtype, psi0_dev, n, dt, kry_m, psit_dev, true);
+}
+
+extern "C" int sd_krylov_evolve_sharded(sd_ctx *ctx, const sd_model *m, sd_comm *comm, int dtype, const void *psi0_dev,
+                                        int64_t n_local, double dt, int kry_m, void *psit_dev) {
+  Op op; RC(op.init(ctx, m, comm));
+  return krylov_evolve_core(op, dtype, psi0_dev, n_local, dt, kry_m, psit_dev, true);
 }
 
 // chebyshev_time_evolve on device vectors: psi0_dev (c128, n elements) is read, psit_dev receives psi(t); they may be the
 // same buffer (psi0 is copied into the recursion's own vectors first).  host_in / host_out select the host-pointer form.
-static int chebyshev_evolve_core(sd_ctx *ctx, const sd_model *m, const void *psi0, bool host_in, int64_t n, double dt, int cheb_n,
+static int chebyshev_evolve_core(Op &op, const void *psi0, bool host_in, int64_t n, double dt, int cheb_n,
                                  double Emin, double Emax, void *psit, bool host_out) {
-  RC(check_unsharded(ctx, m));
+  sd_ctx *ctx = op.ctx;
   if (!psi0 || !psit) return sd_set_err(ctx, SD_EARG, "null vector");
-  if (n != m->N) return sd_set_err(ctx, SD_EDIM, "vector length does not match the basis dimension");
+  if (n != op.n) return sd_set_err(ctx, SD_EDIM, "vector length does not match the (local) basis dimension");
   if (cheb_n < 1) return sd_set_err(ctx, SD_EARG, "cheb_n must be >= 1");               // :65
   const double a = (Emax - Emin) / (2 * 0.9999), b = (Emax + Emin) / 2;                   // :70-71
   std::vector<double> c(2 * (size_t)cheb_n);
@@ -611,7 +724,7 @@ static int chebyshev_evolve_core(sd_ctx *ctx, const sd_model *m, const void *psi
   if (host_out) { RC(ptb.alloc(ctx, 2 * n)); pt.p = ptb.p; }
   else pt.p = (double *)psit;
   sd_epi_args ea; ea.a = a; ea.b = b;
-  RC(sd_launch_apply(ctx, m, SD_C128, pcur, pprev, SD_EPI_RESCALE, ea));                  // :93
+  RC(op.apply(SD_C128, pcur, pprev, SD_EPI_RESCALE, ea));                                 // :93
   RC(sd_k_cheb_init(ctx, pt.p, pprev, pcur, n, c[0], c[1], cheb_n >= 2 ? c[2] : 0.0, cheb_n >= 2 ? c[3] : 0.0,
                     cheb_n >= 2));                                                        // :96-102
   // :110-121, one fused pass per term.  Terms are taken in pairs: the first of a pair only advances the recurrence, the
@@ -621,16 +734,16 @@ static int chebyshev_evolve_core(sd_ctx *ctx, const sd_model *m, const void *psi
   ea.accv = pt.p;
   if ((cheb_n - 2) % 2 == 1) {
     ea.prev = pprev; ea.c_re = c[2 * k]; ea.c_im = c[2 * k + 1];
-    RC(sd_launch_apply(ctx, m, SD_C128, pnext, pcur, SD_EPI_CHEB, ea));
+    RC(op.apply(SD_C128, pnext, pcur, SD_EPI_CHEB, ea));
     double *t = pprev; pprev = pcur; pcur = pnext; pnext = t;
     ++k;
   }
   for (; k + 1 <= cheb_n - 1; k += 2) {
     ea.prev = pprev;
-    RC(sd_launch_apply(ctx, m, SD_C128, pnext, pcur, SD_EPI_RECUR, ea));                  // phi_k
+    RC(op.apply(SD_C128, pnext, pcur, SD_EPI_RECUR, ea));                                 // phi_k
     { double *t = pprev; pprev = pcur; pcur = pnext; pnext = t; }
     ea.prev = pprev; ea.c0_re = c[2 * k]; ea.c0_im = c[2 * k + 1]; ea.c_re = c[2 * k + 2]; ea.c_im = c[2 * k + 3];
-    RC(sd_launch_apply(ctx, m, SD_C128, pnext, pcur, SD_EPI_CHEB2, ea));                  // phi_{k+1}; psi_t += c_k phi_k + c_{k+1} phi_{k+1}
+    RC(op.apply(SD_C128, pnext, pcur, SD_EPI_CHEB2, ea));                                 // phi_{k+1}; psi_t += c_k phi_k + c_{k+1} phi_{k+1}
     { double *t = pprev; pprev = pcur; pcur = pnext; pnext = t; }
   }
   if (host_out) RC(d2h(ctx, psit, pt.p, 2 * n));
@@ -640,43 +753,66 @@ static int chebyshev_evolve_core(sd_ctx *ctx, const sd_model *m, const void *psi
 
 extern "C" int sd_chebyshev_evolve(sd_ctx *ctx, const sd_model *m, const void *psi0, int64_t n, double dt, int cheb_n,
                                    double Emin, double Emax, void *psit) {
-  return chebyshev_evolve_core(ctx, m, psi0, true, n, dt, cheb_n, Emin, Emax, psit, true);
+  Op op; RC(op.init(ctx, m, nullptr));
+  return chebyshev_evolve_core(op, psi0, true, n, dt, cheb_n, Emin, Emax, psit, true);
 }
 
 extern "C" int sd_chebyshev_evolve_dev(sd_ctx *ctx, const sd_model *m, const void *psi0_dev, int64_t n, double dt, int cheb_n,
                                        double Emin, double Emax, void *psit_dev) {
-  return chebyshev_evolve_core(ctx, m, psi0_dev, false, n, dt, cheb_n, Emin, Emax, psit_dev, false);
+  Op op; RC(op.init(ctx, m, nullptr));
+  return chebyshev_evolve_core(op, psi0_dev, false, n, dt, cheb_n, Emin, Emax, psit_dev, false);
+}
+
+extern "C" int sd_chebyshev_evolve_sharded(sd_ctx *ctx, const sd_model *m, sd_comm *comm, const void *psi0_dev,
+                                           int64_t n_local, double dt, int cheb_n, double Emin, double Emax, void *psit_dev) {
+  Op op; RC(op.init(ctx, m, comm));
+  return chebyshev_evolve_core(op, psi0_dev, false, n_local, dt, cheb_n, Emin, Emax, psit_dev, false);
 }
 
 extern "C" int sd_kpm_moments(sd_ctx *ctx, const sd_model *m, const void *phi, int64_t n, int M, double a, double b,
                               double *mu) {
-  RC(check_unsharded(ctx, m));
+  Op op; RC(op.init(ctx, m, nullptr));
   if (n != m->N) return sd_set_err(ctx, SD_EDIM, "vector length does not match the basis dimension");
   if (!phi || !mu) return sd_set_err(ctx, SD_EARG, "null argument");
   DBuf ph; RC(ph.alloc(ctx, 2 * n));
   RC(h2d(ctx, ph.p, phi, 2 * n));
-  return moments_dev(ctx, m, ph.p, M, a, b, mu);
+  return moments_dev(op, ph.p, M, a, b, mu);
 }
 
-extern "C" int sd_kpm_sqw(sd_ctx *ctx, const sd_model *m, int dtype, const void *psi0, int64_t n, const double *q, int Qn,
-                          const double *omega, int W, int have_ab, double a, double b, int kpm_m, int kernel,
-                          uint64_t seed, double *Smat) {
-  RC(check_unsharded(ctx, m));
-  if (n != m->N) return sd_set_err(ctx, SD_EDIM, "vector length does not match the basis dimension");
+extern "C" int sd_kpm_moments_sharded(sd_ctx *ctx, const sd_model *m, sd_comm *comm, const void *phi_dev, int64_t n_local,
+                                      int M, double a, double b, double *mu) {
+  Op op; RC(op.init(ctx, m, comm));
+  if (n_local != op.n) return sd_set_err(ctx, SD_EDIM, "vector length does not match the local basis dimension");
+  if (!phi_dev || !mu) return sd_set_err(ctx, SD_EARG, "null argument");
+  RC(moments_dev(op, (const double *)phi_dev, M, a, b, mu));
+  SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SD_OK;
+}
+
+// kpm_sqw (src/KPM_Sqw.jl:191-256); psi0: host vector (unsharded form) or this rank's rows on the device
+static int kpm_sqw_core(Op &op, int dtype, const void *psi0, bool on_dev, int64_t n, const double *q, int Qn,
+                        const double *omega, int W, int have_ab, double a, double b, int kpm_m, int kernel, uint64_t seed,
+                        double *Smat) {
+  sd_ctx *ctx = op.ctx;
+  const sd_model *m = op.m;
+  if (n != op.n) return sd_set_err(ctx, SD_EDIM, "vector length does not match the (local) basis dimension");
   if (dtype != SD_F64 && dtype != SD_C128) return sd_set_err(ctx, SD_EARG, "bad dtype");
   if (kpm_m < 2) return sd_set_err(ctx, SD_EARG, "kpm_m must be >= 2");
+  if (!psi0 || !Smat || (Qn > 0 && !q) || (W > 0 && !omega)) return sd_set_err(ctx, SD_EARG, "null argument");
   const int nc = dtype == SD_C128 ? 2 : 1;
   DBuf in, psic, tmp, phi;
-  RC(in.alloc(ctx, nc * n)); RC(psic.alloc(ctx, 2 * n)); RC(tmp.alloc(ctx, 2 * n)); RC(phi.alloc(ctx, 2 * n));
-  RC(h2d(ctx, in.p, psi0, nc * n));
-  RC(sd_k_promote(ctx, psic.p, in.p, nc, n));                                             // :202
+  RC(psic.alloc(ctx, 2 * n)); RC(tmp.alloc(ctx, 2 * n)); RC(phi.alloc(ctx, 2 * n));
+  const double *inp = (const double *)psi0;
+  if (!on_dev) { RC(in.alloc(ctx, nc * n)); RC(h2d(ctx, in.p, psi0, nc * n)); inp = in.p; }
+  RC(sd_k_promote(ctx, psic.p, inp, nc, n));                                              // :202
   sd_epi_args ea;
-  RC(sd_launch_apply(ctx, m, SD_C128, tmp.p, psic.p, SD_EPI_DOT, ea));                    // :208-209
+  RC(op.apply(SD_C128, tmp.p, psic.p, SD_EPI_DOT, ea));                                   // :208-209
+  RC(op.reduce(ctx->d_scalars + 0, 2));
   double s[2]; RC(sd_read_scalars(ctx, 0, 2, s));
   const double E0 = s[0];
   if (!have_ab) {                                                                         // :212-214
     double Emin, Emax;
-    RC(sd_energy_bounds(ctx, m, 80, nullptr, nullptr, seed, &Emin, &Emax));
+    RC(energy_bounds_core(op, 80, nullptr, nullptr, true, seed, &Emin, &Emax));
     sd_kpm_rescaling_from_bounds(Emin, Emax, &a, &b);
   }
   std::vector<double> mu(kpm_m), g(kpm_m);
@@ -685,21 +821,36 @@ extern "C" int sd_kpm_sqw(sd_ctx *ctx, const sd_model *m, int dtype, const void 
   for (int iq = 0; iq < Qn; ++iq) {                                                       // :218 (serial over q)
     double *Srow = Smat + (size_t)iq * W;
     RC(sd_launch_szq(ctx, m, SD_C128, psic.p, q[iq], phi.p));                             // :223
-    const double norm_phi = norm_dev(ctx, phi.p, 2 * n, &rc); RC(rc);
+    const double norm_phi = norm_dev(op, phi.p, 2 * n, &rc); RC(rc);
     if (norm_phi == 0) { for (int iw = 0; iw < W; ++iw) Srow[iw] = 0.0; continue; }       // :226-229
     RC(sd_k_scale_div(ctx, phi.p, phi.p, 2 * n, norm_phi));                               // :231
-    RC(moments_dev(ctx, m, phi.p, kpm_m, a, b, mu.data()));
+    RC(moments_dev(op, phi.p, kpm_m, a, b, mu.data()));
     for (int k = 0; k < kpm_m; ++k) mu[k] *= g[k];                                        // :53
     sd_kpm_reconstruct(mu.data(), kpm_m, omega, W, a, b, E0, Srow);
     const double n2 = norm_phi * norm_phi;
     for (int iw = 0; iw < W; ++iw) Srow[iw] *= n2;                                        // :252
   }
+  SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return SD_OK;
+}
+
+extern "C" int sd_kpm_sqw(sd_ctx *ctx, const sd_model *m, int dtype, const void *psi0, int64_t n, const double *q, int Qn,
+                          const double *omega, int W, int have_ab, double a, double b, int kpm_m, int kernel,
+                          uint64_t seed, double *Smat) {
+  Op op; RC(op.init(ctx, m, nullptr));
+  return kpm_sqw_core(op, dtype, psi0, false, n, q, Qn, omega, W, have_ab, a, b, kpm_m, kernel, seed, Smat);
+}
+
+extern "C" int sd_kpm_sqw_sharded(sd_ctx *ctx, const sd_model *m, sd_comm *comm, int dtype, const void *psi0_dev,
+                                  int64_t n_local, const double *q, int Qn, const double *omega, int W, int have_ab, double a,
+                                  double b, int kpm_m, int kernel, uint64_t seed, double *Smat) {
+  Op op; RC(op.init(ctx, m, comm));
+  return kpm_sqw_core(op, dtype, psi0_dev, true, n_local, q, Qn, omega, W, have_ab, a, b, kpm_m, kernel, seed, Smat);
 }
 
 extern "C" int sd_lanczos_sqw(sd_ctx *ctx, const sd_model *m, int dtype, const void *psi0, int64_t n, const double *q,
                               int Qn, const double *omega, int W, int lanc_m, double eta, int broaden, double *Smat) {
-  RC(check_unsharded(ctx, m));
+  Op op; RC(op.init(ctx, m, nullptr));
   if (n != m->N) return sd_set_err(ctx, SD_EDIM, "vector length does not match the basis dimension");
   if (dtype != SD_F64 && dtype != SD_C128) return sd_set_err(ctx, SD_EARG, "bad dtype");
   if (broaden != SD_BROADEN_LORENTZ && broaden != SD_BROADEN_GAUSS) return sd_set_err(ctx, SD_EARG, "unknown broadening");
@@ -711,24 +862,22 @@ extern "C" int sd_lanczos_sqw(sd_ctx *ctx, const sd_model *m, int dtype, const v
   RC(sd_k_promote(ctx, psic.p, in.p, nc, n));
   sd_epi_args ea;
   RC(sd_launch_apply(ctx, m, SD_C128, tmp.p, psic.p, SD_EPI_PLAIN, ea));                  // src/LanczosSqw.jl:58
-  // E0 = real(dot(conj(psi0c), tmp)) = Re sum psi_i*tmp_i (sic, :59): conj(conj(psi)).tmp -> use dot with conj(psi)
-  // Re sum (pr + i pi)(tr + i ti) = sum pr*tr - pi*ti.  Computed as dot(psi, tmp') with tmp' = conj(tmp):
-  // Re<psi|conj(tmp)> = sum pr*tr - pi*ti.  We get it from two real dots of the interleaved arrays.
-  std::vector<double> hp(2 * (size_t)n), ht(2 * (size_t)n);
-  RC(d2h(ctx, hp.data(), psic.p, 2 * n)); RC(d2h(ctx, ht.data(), tmp.p, 2 * n));
-  double E0 = 0.0;
-  for (int64_t i = 0; i < n; ++i) E0 += hp[2 * i] * ht[2 * i] - hp[2 * i + 1] * ht[2 * i + 1];
+  // E0 = real(dot(conj(psi0c), tmp)) (sic, :59): dot conjugates its first argument again, so this is Re sum psi_i*tmp_i,
+  // the product sum WITHOUT conjugation (equal to <psi|H|psi> for a real psi0).  Reduced on the device.
+  RC(sd_k_dotu(ctx, psic.p, tmp.p, n, 4));
+  double e0s[2]; RC(sd_read_scalars(ctx, 4, 2, e0s));
+  const double E0 = e0s[0];
   const int mm = (int)std::min<int64_t>(lanc_m, n);
   std::vector<double> alpha(mm), beta(std::max(mm, 1));
   int rc = 0;
   for (int iq = 0; iq < Qn; ++iq) {
     double *Srow = Smat + (size_t)iq * W;
     RC(sd_launch_szq(ctx, m, SD_C128, psic.p, q[iq], phi.p));
-    const double normv = norm_dev(ctx, phi.p, 2 * n, &rc); RC(rc);
+    const double normv = norm_dev(op, phi.p, 2 * n, &rc); RC(rc);
     if (normv == 0) { for (int iw = 0; iw < W; ++iw) Srow[iw] = 0.0; continue; }          // :67-70
     RC(sd_k_scale_div(ctx, phi.p, phi.p, 2 * n, normv));
     int m_eff = 0;
-    RC(tridiag_dev(ctx, m, phi.p, lanc_m, 1e-12, alpha.data(), beta.data(), &m_eff));     // :73
+    RC(tridiag_dev(op, phi.p, lanc_m, 1e-12, alpha.data(), beta.data(), &m_eff));     // :73
     int rs = sd_spectral_from_tridiagonal(alpha.data(), beta.data(), m_eff, normv, E0, omega, W, eta, broaden, Srow);
     if (rs) return sd_set_err(ctx, rs, "spectral_from_tridiagonal failed");
   }

@@ -98,7 +98,6 @@ struct sd_dev_model {
   int n_singles;
   int n_interior;                // sharded plans: the first n_interior single tiles read no halo (their partners are all owned)
   int tile_off;                  // first tile of this launch (lets the interior / boundary parts run as separate launches)
-  int part_off;                  // first tile of the launched part: per-tile partial sums are stored relative to it
   const uint32_t *single_prefix; // the local tiles in launch order (k_apply_tiled)
   const int64_t *single_base;
   const sd_tile_rec *single_rec;
@@ -190,6 +189,7 @@ int sd_launch_szq(sd_ctx *ctx, const sd_model *m, int dtype_in, const void *psi0
 // Reductions write their result to ctx->d_scalars[slot..] (device memory) in a
 // fixed, deterministic order; sd_read_scalars copies them to the host.
 int sd_k_dot(sd_ctx *ctx, int nc, const double *x, const double *y, int64_t N, int slot);  // conj(x).y -> [slot]=re,[slot+1]=im
+int sd_k_dotu(sd_ctx *ctx, const double *x, const double *y, int64_t N, int slot);          // complex sum x_i*y_i, NO conjugation -> [slot]=re,[slot+1]=im
 int sd_k_nrm2sq(sd_ctx *ctx, const double *x, int64_t n, int slot);
 int sd_k_krylov_update_nrm_devs(sd_ctx *ctx, double *w, const double *v, const double *u, int64_t N, const double *alpha_dev,
                                 const double *b_dev, double *store_alpha, int slot);
@@ -224,6 +224,12 @@ double sd_randn_host(uint64_t seed, uint64_t k);
 // doubles of ctx->d_partials (long lists are summed in two stages)
 #define SD_RED_STAGE_BLOCKS 512
 int sd_reduce_pairs(sd_ctx *ctx, int64_t n, double *dst);
+// ---- communicators (comm.cpp): all three are no-ops for a null communicator or an unsharded model ----
+int sd_comm_nranks(const sd_comm *c);
+int sd_comm_exchange_start(sd_ctx *ctx, sd_comm *c, const sd_model *m, int dtype, const void *src, void *halo);
+int sd_comm_exchange_wait(sd_ctx *ctx, sd_comm *c, const sd_model *m);
+int sd_comm_allreduce_dev(sd_ctx *ctx, sd_comm *c, double *vals_dev, int count);   // in place, ordered on ctx->stream
+
 // grows ctx->d_partials to at least `doubles` entries (scratch for per-workgroup partial sums)
 int sd_ensure_partials(sd_ctx *ctx, size_t doubles);
 

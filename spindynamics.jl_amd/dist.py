@@ -30,6 +30,121 @@ class _StagedRequests:
         self.dst_dev.copy_(self.dst_host)
 
 
+class _DevMem:
+    """A raw device pointer as a __cuda_array_interface__ object (Float64 view), so that torch can wrap it without a copy."""
+
+    def __init__(self, ptr, n_doubles):
+        self.__cuda_array_interface__ = {"shape": (int(n_doubles),), "typestr": "<f8", "data": (int(ptr), False),
+                                         "version": 3, "strides": None}
+
+
+def _dev_tensor(ptr, n_doubles, device):
+    import torch
+    return torch.as_tensor(_DevMem(ptr, n_doubles), device=device)
+
+
+class TorchComm:
+    """sd_comm (include/spindyn.h) whose callbacks move the bytes with torch.distributed: what the C recursion-level entry
+    points (sd_*_sharded) call for the halo exchange of each apply and for the sum of the scalars of each reduction.
+    Backend "nccl" (= RCCL over xGMI): device to device; "gloo" (rehearsals with several ranks on one GPU): staged
+    through the host."""
+
+    def __init__(self, op, device, group=None):
+        import torch.distributed as dist
+        self.op, self.device, self.group = op, device, group
+        self.backend = dist.get_backend(group)
+        self._reqs = []
+        self._err = None
+        self._cbs = _lib.sd_comm_callbacks(None, _lib.EXCHANGE_START_FN(self._start), _lib.EXCHANGE_WAIT_FN(self._wait),
+                                           _lib.ALLREDUCE_FN(self._allreduce))     # keeps the trampolines alive
+        self.h = C.c_void_p()
+        check(lib().sd_comm_from_callbacks(C.byref(self._cbs), op.rank, op.world, C.byref(self.h)))
+
+    def _start(self, _user, dtype, src_ptr, halo_ptr):
+        try:
+            import torch
+            import torch.distributed as dist
+            op = self.op
+            per = 2 if dtype == _lib.SD_C128 else 1
+            n_src = op.n_send if op.mode == "class" else op.n_local
+            src = _dev_tensor(src_ptr, max(n_src, 1) * per, self.device)
+            dst = _dev_tensor(halo_ptr, max(op.n_halo, 1) * per, self.device)
+            staged = self.backend == "gloo"
+            if staged:
+                torch.cuda.current_stream(self.device).synchronize()      # the pack kernel of the C side has finished
+                dst_dev, src, dst = dst, src.cpu(), torch.empty(dst.shape, dtype=dst.dtype)
+            nl = op.n_local
+            ops = []
+            for (peer, off, cnt, _g) in op.recv_slabs:
+                ops.append(dist.P2POp(dist.irecv, dst[(off - nl) * per:(off - nl + cnt) * per], peer, self.group))
+            for (peer, off, cnt, _g) in op.send_slabs:
+                ops.append(dist.P2POp(dist.isend, src[off * per:(off + cnt) * per], peer, self.group))
+            reqs = dist.batch_isend_irecv(ops) if ops else []
+            self._reqs = [_StagedRequests(reqs, dst_dev, dst)] if (staged and reqs) else reqs
+            return 0
+        except Exception as e:      # an exception must not unwind through the C frames
+            self._err = e
+            return 1
+
+    def _wait(self, _user):
+        try:
+            for r in self._reqs:
+                r.wait()
+            self._reqs = []
+            return 0
+        except Exception as e:
+            self._err = e
+            return 1
+
+    def _allreduce(self, _user, vals, count):
+        try:
+            import numpy as np
+            import torch
+            import torch.distributed as dist
+            a = np.ctypeslib.as_array(vals, shape=(count,))
+            t = torch.from_numpy(a.copy())
+            if self.backend == "nccl":
+                t = t.to(self.device)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            a[:] = t.cpu().numpy()
+            return 0
+        except Exception as e:
+            self._err = e
+            return 1
+
+    def close(self):
+        if self.h:
+            lib().sd_comm_destroy(self.h)
+            self.h = None
+
+
+class RcclComm:
+    """sd_comm on RCCL itself (sd_comm_rccl_create): grouped ncclSend/ncclRecv beside the interior tiles and ncclAllReduce
+    of the device scalars, all queued on HIP streams by the C side -- a recursion step never touches the host.  The
+    128-byte id is made on rank 0 and broadcast with torch.distributed (any transport would do)."""
+
+    def __init__(self, op, device, group=None):
+        import torch
+        import torch.distributed as dist
+        idbuf = (C.c_ubyte * 128)()
+        if op.rank == 0:
+            check(lib().sd_comm_rccl_unique_id(idbuf))
+        t = torch.tensor(list(idbuf), dtype=torch.uint8)
+        if dist.get_backend(group) == "nccl":
+            t = t.to(device)
+        dist.broadcast(t, 0, group=group)
+        idbuf = (C.c_ubyte * 128)(*[int(v) for v in t.cpu().tolist()])
+        self.h = C.c_void_p()
+        m = op.model
+        check(lib().sd_comm_rccl_create(m.ctx.h, op.rank, op.world, idbuf, C.byref(self.h)), m.ctx.h)
+        self._err = None
+
+    def close(self):
+        if self.h:
+            lib().sd_comm_destroy(self.h)
+            self.h = None
+
+
 class ShardedOperator:
     def __init__(self, model, rank, world, exchange_fn=None, mode=None, pack_fn=None, reduce_fn=None):
         self.model = model
@@ -48,6 +163,32 @@ class ShardedOperator:
         self.row_lo, self.row_hi = int(info.row_lo), int(info.row_hi)
         self.recv_slabs, self.send_slabs = model.shard_slabs()
         self._halo = {}
+        self._comm = None
+
+    def comm(self, device, group=None):
+        """The communicator handed to the C recursion-level entry points: RCCL itself with SD_COMM=rccl, else
+        torch.distributed behind callbacks (None for a single rank)."""
+        import os
+        if self.world == 1:
+            return None
+        if self._exchange_fn is not None:
+            raise _lib.ArgumentError("virtual shards (one process) cover single applies only: the recursions need real ranks")
+        if self._comm is None:
+            kind = os.environ.get("SD_COMM", "torch")
+            self._comm = RcclComm(self, device, group) if kind == "rccl" else TorchComm(self, device, group)
+        return self._comm
+
+    def _call(self, fn, x, *args, group=None):
+        """Run a sd_*_sharded entry point on the stream torch is using for x's device."""
+        import torch
+        m = self.model
+        m.ctx.set_stream(torch.cuda.current_stream(x.device).cuda_stream)
+        cm = self.comm(x.device, group)
+        rc = fn(m.ctx.h, m.h, cm.h if cm is not None else None, *args)
+        if rc != _lib.SD_OK and cm is not None and getattr(cm, "_err", None) is not None:
+            err, cm._err = cm._err, None
+            raise err
+        check(rc, m.ctx.h)
 
     # ---- buffers ----
     def empty(self, dtype, device):
@@ -175,35 +316,26 @@ class ShardedOperator:
 
     def chebyshev_time_evolve(self, psi0, dt, cheb_n=100, Ebounds=(-1.0, 1.0), group=None):
         """chebyshev_time_evolve (src/TimeEvolution/Chebyshev.jl:61-124) on a sharded ComplexF64 state (psi0 = this
-        rank's owned elements).  Every term is one halo exchange + one fused device pass.  Returns psi(t) (owned part)."""
+        rank's owned elements): sd_chebyshev_evolve_sharded -- every term is one halo exchange + one fused device pass,
+        terms in pairs, nothing but the recursion's three vectors and psi(t) allocated.  Returns psi(t) (owned part)."""
         import torch
-        from .solvers import chebyshev_coeffs
         if int(cheb_n) < 1:
             raise AssertionError("cheb_n must be >= 1")
-        Emin, Emax = Ebounds
-        a = (Emax - Emin) / (2 * 0.9999)
-        b = (Emax + Emin) / 2
-        c = chebyshev_coeffs(cheb_n, a, b, dt)
-        prev, cur, nxt = psi0.clone(), torch.zeros_like(psi0), torch.zeros_like(psi0)
-        self.apply_rescaled(cur, prev, a, b, group)                       # phi_curr = H~ phi_prev  (Chebyshev.jl:93)
-        acc = torch.zeros_like(psi0)                                     # psi_t = c0*T0 + c1*T1  (Chebyshev.jl:96-102)
-        acc += complex(c[0]) * prev
-        if cheb_n >= 2:
-            acc += complex(c[1]) * cur
-        # terms in pairs: the first of a pair only advances the recurrence (epilogue 3), the second adds both terms to psi_t
-        # in order (sd_apply_sharded_cheb2_dev) -- same bits as one accumulation per term, psi_t touched half as often
-        k = 2
-        if int(cheb_n) > 2 and (int(cheb_n) - 2) % 2 == 1:
-            self.cheb_step(nxt, cur, prev, acc, a, b, complex(c[k]), group)
-            prev, cur, nxt = cur, nxt, prev
-            k += 1
-        while k + 1 <= int(cheb_n) - 1:
-            self._apply(nxt, cur, group, 3, a=a, b=b, prev=prev)
-            prev, cur, nxt = cur, nxt, prev
-            self._apply(nxt, cur, group, 4, a=a, b=b, c=complex(c[k + 1]), c0=complex(c[k]), prev=prev, acc=acc)
-            prev, cur, nxt = cur, nxt, prev
-            k += 2
-        return acc
+        psi0 = psi0.to(torch.complex128).contiguous()
+        out = torch.empty_like(psi0)
+        self._call(lib().sd_chebyshev_evolve_sharded, psi0, psi0.data_ptr(), self.n_local, float(dt), int(cheb_n),
+                   float(Ebounds[0]), float(Ebounds[1]), out.data_ptr(), group=group)
+        return out
+
+    def krylov_time_evolve(self, psi0, dt, kry_m=30, group=None):
+        """krylov_time_evolve (src/TimeEvolution/Krylov.jl:136-192) on a sharded state: sd_krylov_evolve_sharded."""
+        import torch
+        psi0 = psi0.contiguous()
+        code = _lib.SD_C128 if psi0.is_complex() else _lib.SD_F64
+        out = torch.empty(self.n_local, dtype=torch.complex128, device=psi0.device)
+        self._call(lib().sd_krylov_evolve_sharded, psi0, code, psi0.data_ptr(), self.n_local, float(dt), int(kry_m),
+                   out.data_ptr(), group=group)
+        return out
 
     # ---- KPM on a sharded state (BASELINE config 5: L=36 over 8 GPUs) ----
     def _allreduce(self, vals, device, group=None):
@@ -242,124 +374,64 @@ class ShardedOperator:
         return phi
 
     def kpm_moments(self, phi, M, a, b, group=None, doubling=True):
-        """compute_chebyshev_moments (src/KPM_Sqw.jl:95-128) for a normalised sharded phi; returns mu[0..M).
-        doubling (default): two moments per apply, mu_2n = 2<v_n|v_n> - mu_0, mu_2n+1 = 2Re<v_n|v_n+1> - mu_1;
-        doubling=False: the reference's loop, one moment <phi|v_k> per apply."""
-        import ctypes as C
+        """compute_chebyshev_moments (src/KPM_Sqw.jl:95-128) for a normalised sharded phi; returns mu[0..M):
+        sd_kpm_moments_sharded.  doubling (default): two moments per apply, mu_2n = 2<v_n|v_n> - mu_0,
+        mu_2n+1 = 2Re<v_n|v_n+1> - mu_1; doubling=False: the reference's loop, one moment <phi|v_k> per apply."""
         import numpy as np
-        import torch
         if M < 2:
             raise _lib.ArgumentError("kpm_m must be >= 2")
-        m = self.model
-        mu = np.zeros(M)
-        v_prev, v_curr, v_next = phi.clone(), torch.empty_like(phi), torch.empty_like(phi)
-        mu[0] = self.dot(phi, v_prev, group).real
-        sums = (C.c_double * 2)()
-        nsteps = (M // 2) if doubling else (M - 1)      # applies: v_1 .. v_nsteps
-        for k in range(1, nsteps + 1):
-            src = v_prev if k == 1 else v_curr
-            dst = v_curr if k == 1 else v_next
-            halo = self.exchange(src, group)
-            loc = [0.0, 0.0]
-            if self.n_local:
-                m.ctx.set_stream(torch.cuda.current_stream(phi.device).cuda_stream)
-                check(lib().sd_kpm_step_sharded_dev(m.ctx.h, m.h, dst.data_ptr(), src.data_ptr(),
-                                                    halo.data_ptr() if self.n_halo else None,
-                                                    v_prev.data_ptr(), None if doubling else phi.data_ptr(), self.n_local,
-                                                    float(a), float(b), 1 if k == 1 else 0, sums), m.ctx.h)
-                loc = [sums[0], sums[1]]
-            tot = self._allreduce(loc, phi.device, group)
-            if doubling:                                # tot = [Re<v_{k-1}|v_k>, |v_k|^2]
-                if k == 1:
-                    mu[1] = tot[0]
-                elif 2 * k - 1 <= M - 1:
-                    mu[2 * k - 1] = 2.0 * tot[0] - mu[1]
-                if 2 * k <= M - 1:
-                    mu[2 * k] = 2.0 * tot[1] - mu[0]
-                if float(np.sqrt(tot[1])) > 1e3:        # bounds do not contain the spectrum: mirror the reference's loop
-                    return self.kpm_moments(phi, M, a, b, group, doubling=False)
-            else:
-                mu[k] = tot[0]
-            if k >= 2:
-                if not doubling:
-                    nv = float(np.sqrt(tot[1]))
-                    if nv > 1e3:                       # src/KPM_Sqw.jl:117-121
-                        v_next /= nv
-                v_prev, v_curr, v_next = v_curr, v_next, v_prev
+        mu = np.zeros(int(M))
+        self.model.ctx.set_kpm_doubling(bool(doubling))
+        try:
+            phi = phi.contiguous()
+            self._call(lib().sd_kpm_moments_sharded, phi, phi.data_ptr(), self.n_local, int(M), float(a), float(b),
+                       mu.ctypes.data_as(C.POINTER(C.c_double)), group=group)
+        finally:
+            self.model.ctx.set_kpm_doubling(True)
         return mu
 
     # ---- Lanczos on a sharded state (energy bounds for the sharded KPM / Chebyshev drivers) ----
     def lanczos_extremal(self, lanc_m=100, tol=1e-12, psi0=None, seed=0, group=None, device="cuda", negate=False):
-        """lanczos_extremal (src/Lanczos.jl:27-84) with the vectors sharded: returns (Emin, Emax) of the Lanczos matrix.
-        psi0: this rank's owned part of the start vector (ComplexF64); default: the counter-based N(0,1) vector of `seed`
-        (identical for every sharding).  One halo exchange + one fused apply per step; alpha, beta are all-reduced."""
-        import numpy as np
+        """lanczos_extremal (src/Lanczos.jl:27-84) with the vectors sharded: sd_lanczos_extremal_sharded, returns
+        (Emin, Emax) of the Lanczos matrix.  psi0: this rank's owned part of the start vector (ComplexF64); default: the
+        counter-based N(0,1) vector of `seed` (identical for every sharding).  alpha_j and beta_j are summed over the ranks
+        on the device (RCCL) or through one host round trip each (torch.distributed callbacks)."""
         import torch
-        from .solvers import symtridiag_eig
-        N = self.model.N
-        mm = int(min(int(lanc_m), N))
-        if mm < 1:
+        if int(lanc_m) < 1:
             raise _lib.ArgumentError("lanc_m must be >= 1")
-        if psi0 is None:
-            v_prev = self.fill_randn(self.empty(torch.complex128, device), seed)
-        else:
-            v_prev = psi0.to(torch.complex128).clone()
-        nrm = self.norm(v_prev, group)
-        if nrm == 0:
-            raise _lib.ZeroNormError("starting vector has zero norm")
-        v_prev /= nrm                                                       # :40
-        v_curr = torch.zeros_like(v_prev)
-        w = torch.empty_like(v_prev)
-        alpha, beta = np.zeros(mm), np.zeros(mm)
-        actual = mm
-        for j in range(1, mm + 1):
-            self.apply(w, v_prev, group)                                    # :51
-            if negate:                                                      # apply_H_neg! of estimate_energy_bounds (:260-264)
-                w.neg_()
-            alpha[j - 1] = self.dot(v_prev, w, group).real                  # :55
-            if j == 1:
-                w -= alpha[j - 1] * v_prev                                  # :59
-            else:
-                w -= alpha[j - 1] * v_prev + beta[j - 2] * v_curr
-            if j < mm:
-                beta[j - 1] = self.norm(w, group)                           # :65
-                if beta[j - 1] < tol:                                       # :66-70
-                    actual = j
-                    break
-                v_curr, v_prev = v_prev, v_curr
-                torch.div(w, beta[j - 1], out=v_prev)                       # :71
-        ev = symtridiag_eig(alpha[:actual], beta[:max(actual - 1, 0)], vectors=False)
-        return float(ev[0]), float(ev[-1])
+        lo, hi = C.c_double(), C.c_double()
+        anchor = psi0 if psi0 is not None else torch.empty(0, device=device)
+        if psi0 is not None:
+            psi0 = psi0.to(torch.complex128).contiguous()
+            if float(self.norm(psi0, group)) == 0.0:
+                raise _lib.ZeroNormError("starting vector has zero norm")
+        self._call(lib().sd_lanczos_extremal_sharded, anchor, int(lanc_m), float(tol),
+                   psi0.data_ptr() if psi0 is not None else None, int(seed), 1 if negate else 0, C.byref(lo), C.byref(hi),
+                   group=group)
+        return lo.value, hi.value
 
     def estimate_energy_bounds(self, lanc_m=80, seed=0, group=None, device="cuda"):
         """estimate_energy_bounds (src/Lanczos.jl:255-271): Emax from a Lanczos run on H, Emin = -Emax of a run on -H."""
-        _, Emax = self.lanczos_extremal(lanc_m, seed=2 * seed + 1, group=group, device=device)
-        _, Emax_neg = self.lanczos_extremal(lanc_m, seed=2 * seed + 2, group=group, device=device, negate=True)
-        return -Emax_neg, Emax
+        import torch
+        lo, hi = C.c_double(), C.c_double()
+        self._call(lib().sd_energy_bounds_sharded, torch.empty(0, device=device), int(lanc_m), int(seed), C.byref(lo),
+                   C.byref(hi), group=group)
+        return lo.value, hi.value
 
     def kpm_sqw(self, psi0, q_list, omega, a=None, b=None, kpm_m=200, kernel="jackson", group=None, seed=0):
-        """kpm_sqw (src/KPM_Sqw.jl:191-256) on a sharded ComplexF64/Float64 psi0; without (a, b) the rescaling is estimated as
-        the reference does (:212-214: energy bounds from two Lanczos runs, lanc_m = 80)."""
+        """kpm_sqw (src/KPM_Sqw.jl:191-256) on a sharded ComplexF64/Float64 psi0: sd_kpm_sqw_sharded; without (a, b) the
+        rescaling is estimated as the reference does (:212-214: energy bounds from two Lanczos runs, lanc_m = 80)."""
         import numpy as np
-        import torch
-        from .solvers import get_kernel, kpm_reconstruct, rescaling_from_bounds
-        if a is None or b is None:
-            Emin, Emax = self.estimate_energy_bounds(80, seed, group, psi0.device)
-            a, b = rescaling_from_bounds(Emin, Emax)
-        psic = psi0.to(torch.complex128)
-        tmp = torch.empty_like(psic)
-        self.apply(tmp, psic, group)
-        E0 = self.dot(psic, tmp, group).real
-        S = np.zeros((len(q_list), len(omega)))
-        g = get_kernel(kpm_m, kernel)
-        for iq, q in enumerate(q_list):
-            phi = self.Sz_q_vector(psic, float(q))
-            n2 = self.dot(phi, phi, group).real
-            if n2 == 0:
-                continue
-            phi /= np.sqrt(n2)
-            mu = self.kpm_moments(phi, kpm_m, a, b, group) * g
-            S[iq] = n2 * kpm_reconstruct(mu, omega, a, b, E0)
+        psi0 = psi0.contiguous()
+        code = _lib.SD_C128 if psi0.is_complex() else _lib.SD_F64
+        q = np.ascontiguousarray(q_list, dtype=np.float64)
+        om = np.ascontiguousarray(omega, dtype=np.float64)
+        S = np.zeros((len(q), len(om)))
+        dp = C.POINTER(C.c_double)
+        have = a is not None and b is not None
+        self._call(lib().sd_kpm_sqw_sharded, psi0, code, psi0.data_ptr(), self.n_local, q.ctypes.data_as(dp), len(q),
+                   om.ctypes.data_as(dp), len(om), 1 if have else 0, float(a) if have else 0.0, float(b) if have else 0.0,
+                   int(kpm_m), _lib.KERNELS.get(kernel, 2), int(seed), S.ctypes.data_as(dp), group=group)
         return S
 
     def fill_randn(self, x, seed):

@@ -135,3 +135,19 @@ def test_large_suffix_tiles(pkg, O, ls, monkeypatch):
         out = np.empty_like(psi)
         pkg.apply_H(out, psi, m)
         assert np.array_equal(out, O.apply_H(r, psi))
+
+
+def test_degenerate_bonds_i_equals_j_are_accepted_as_the_reference_accepts_them(pkg, O):
+    """build_model takes any (i, j, J) tuple (src/SpinModel.jl:23-38).  A hop with i == j never fires (bit_i != bit_j is
+    false, src/Hamiltonian.jl:248-252) and a zz term with i == j adds J/4 to every diagonal element: both must be accepted
+    and reproduce the oracle bit for bit, in a sector and in the full basis."""
+    hop = [(1, 2, 0.5), (3, 3, 0.7), (2, 3, 0.5), (3, 4, 0.5), (5, 5, -1.3), (4, 5, 0.5), (5, 6, 0.25)]
+    zz = [(1, 2, 1.0), (2, 2, 0.5), (2, 3, 1.0), (3, 4, 1.0), (4, 5, 1.0), (5, 6, 1.0)]
+    for nup in (3, None):
+        m = pkg.build_model(6, nup=nup, hopping=hop, zz=zz)
+        r = O.build_model(6, nup=nup, hopping=hop, zz=zz)
+        rng = np.random.default_rng(4)
+        psi = rng.standard_normal(m.N) + 1j * rng.standard_normal(m.N)
+        out = np.empty_like(psi)
+        pkg.apply_H(out, psi, m)
+        assert np.array_equal(out, O.apply_H(r, psi))

@@ -110,6 +110,108 @@ def test_config5_shard_of_L36_exact(pkg, rank):
     halo.fill_(1.0)
     op._launch(out, psi, halo, 0, part=2)
     assert bool((out == (L - 1) / 4).all())
+    if rank == 3:
+        # one KPM moment step of config 5 on this shard (sd_kpm_step_sharded_dev: fused rescale + <phi|v> + |v|^2) with the
+        # uniform state: v_next = ((L-1)/4 - b)/a exactly on every row, and both sums are exact multiples of n_local
+        import ctypes as C
+        a, b = 2.0, 0.25
+        val = ((L - 1) / 4 - b) / a
+        sums = (C.c_double * 2)()
+        model.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        pkg.check(pkg.lib().sd_kpm_step_sharded_dev(model.ctx.h, model.h, out.data_ptr(), psi.data_ptr(), halo.data_ptr(), None,
+                                                    psi.data_ptr(), op.n_local, a, b, 1, sums), model.ctx.h)
+        assert bool((out == val).all())
+        assert sums[0] == val * op.n_local and sums[1] == val * val * op.n_local
+        # second form of the step: v_next = 2 (H v - b v)/a - v_prev with v_prev = v_curr = |F>
+        pkg.check(pkg.lib().sd_kpm_step_sharded_dev(model.ctx.h, model.h, out.data_ptr(), psi.data_ptr(), halo.data_ptr(),
+                                                    psi.data_ptr(), psi.data_ptr(), op.n_local, a, b, 0, sums), model.ctx.h)
+        assert bool((out == 2 * val - 1).all())
+        assert sums[0] == (2 * val - 1) * op.n_local and sums[1] == (2 * val - 1) ** 2 * op.n_local
+
+
+def _random_state(pkg, model, seed):
+    """normalised ComplexF64 state on the device from the library's counter-based generator"""
+    import torch
+    op = pkg.ShardedOperator(model, 0, 1)
+    x = op.empty(torch.complex128, "cuda")
+    op.fill_randn(x, seed)
+    x /= op.norm(x)
+    return op, x
+
+
+def _energy(pkg, op, model, x, scratch):
+    pkg.apply_H(scratch, x, model)
+    return op.dot(x, scratch).real
+
+
+def test_config2_krylov_L28_full_size(pkg):
+    """BASELINE config 2 at its real size (L=28, nup=14, kry_m=30, one MI355X): the CPU oracle cannot follow, so the
+    recursion is checked through what it must conserve -- the norm (1e-12) and <H> (1e-10: V'HV = T makes
+    <psi(t)|H|psi(t)> = T_11 = <psi0|H|psi0> up to the loss of orthogonality of 30 Lanczos vectors)."""
+    import torch
+    L = 28
+    model = pkg.XXZChain(L, nup=L // 2)
+    op, x = _random_state(pkg, model, 11)
+    scratch = torch.empty_like(x)
+    e0 = _energy(pkg, op, model, x, scratch)
+    y = pkg.krylov_time_evolve(x, 0.1, pkg.apply_H, model, kry_m=30)
+    assert abs(op.norm(y) - 1.0) <= 1e-12
+    assert abs(_energy(pkg, op, model, y, scratch) - e0) <= 1e-10
+    assert float((y - x).abs().max()) > 1e-6          # it did move
+    # two steps of dt/2 == one step of dt to the accuracy of the 30-dimensional Krylov space (|H| dt ~ 1.5 here)
+    h = pkg.krylov_time_evolve(pkg.krylov_time_evolve(x, 0.05, pkg.apply_H, model, kry_m=30), 0.05, pkg.apply_H, model, kry_m=30)
+    assert float((h - y).abs().max()) <= 1e-10
+
+
+def test_config3_kpm_moments_L30_full_size(pkg):
+    """BASELINE config 3 at its real size (L=30, nup=15, 1024 moments, one momentum): mu_0 = 1 (1e-12), |mu_n| <= 1, the
+    two-moments-per-apply recursion against the reference's one-moment-per-apply loop on the first 64 moments (1e-12), and
+    the sum rule of the reconstructed S(q,w) (the reference's own test: rtol 5e-3, test/test_KPM.jl:67-91)."""
+    import torch
+    L, M = 30, 1024
+    model = pkg.XXZChain(L, nup=L // 2)
+    op, psi0 = _random_state(pkg, model, 5)
+    scratch = torch.empty_like(psi0)
+    E0 = _energy(pkg, op, model, psi0, scratch)
+    del scratch
+    phi = pkg.Sz_q_vector(model, psi0, float(pkg.momenta(model)[7]))
+    n2 = op.norm(phi) ** 2
+    phi /= n2 ** 0.5
+    del psi0
+    a, b = pkg.rescaling_from_bounds(-13.9, 7.6)        # open L=30 chain: E0 = -13.11..., Emax = (L-1)/4 = 7.25
+    mu = op.kpm_moments(phi, M, a, b)
+    assert abs(mu[0] - 1.0) <= 1e-12
+    assert np.abs(mu).max() <= 1.0 + 1e-12
+    mu_ref = op.kpm_moments(phi, 64, a, b, doubling=False)
+    assert np.abs(mu[:64] - mu_ref).max() <= 1e-12
+    omega = np.linspace(b - a - E0, b + a - E0, 6001)
+    S = n2 * pkg.kpm_reconstruct(mu * pkg.get_kernel(M, "jackson"), omega, a, b, E0)
+    assert (S >= 0).all() and np.isfinite(S).all()
+    assert abs(S.sum() * (omega[1] - omega[0]) - n2) <= 5e-3 * n2
+
+
+def test_config4_chebyshev_L32_full_size(pkg):
+    """BASELINE config 4 at its real size (L=32, nup=16, cheb_n=100, explicit bounds, one rank): the evolution is unitary
+    (norm to 1e-10; the reference does not renormalise, src/TimeEvolution/Chebyshev.jl:123) and two steps of dt/2 equal one
+    step of dt (1e-9 on every element: both are converged, a dt = 4.5 << cheb_n)."""
+    import torch
+    L = 32
+    model = pkg.XXZChain(L, nup=L // 2)
+    free, _ = torch.cuda.mem_get_info()
+    if free < 8 * 16 * model.N + (4 << 30):
+        pytest.skip("not enough device memory")
+    op, x = _random_state(pkg, model, 3)
+    Eb = (-14.6, 8.0)                                 # open L=32 chain: E0 = -13.99..., Emax = 7.75
+    y = pkg.chebyshev_time_evolve(x, 0.4, pkg.apply_H, model, cheb_n=100, Ebounds=Eb)
+    assert abs(op.norm(y) - 1.0) <= 1e-10
+    h = pkg.chebyshev_time_evolve(x, 0.2, pkg.apply_H, model, cheb_n=100, Ebounds=Eb)
+    h = pkg.chebyshev_time_evolve(h, 0.2, pkg.apply_H, model, cheb_n=100, Ebounds=Eb)
+    d = 0.0
+    for k in range(0, model.N, 1 << 27):              # elementwise difference in slices (no third 9.6 GB temporary)
+        d = max(d, float((h[k:k + (1 << 27)] - y[k:k + (1 << 27)]).abs().max()))
+    assert d <= 1e-9
+    assert d < float(y[:1 << 20].abs().max())         # and the state did move away from psi0
+    assert float((y[:1 << 20] - x[:1 << 20]).abs().max()) > 1e-6
 
 
 @pytest.mark.parametrize("mode", ["class", "range"])

@@ -261,11 +261,21 @@ def test_chebyshev_pairing_is_bit_identical_to_one_term_per_pass(pkg, cheb_n):
     got = pkg.chebyshev_time_evolve(psi0, dt, pkg.apply_H, m, cheb_n=cheb_n, Ebounds=Eb)
     got_sharded = pkg.ShardedOperator(m, 0, 1).chebyshev_time_evolve(torch.from_numpy(psi0).cuda(), dt, cheb_n=cheb_n,
                                                                    Ebounds=Eb).cpu().numpy()
-    # the sharded driver forms the first two terms with the same torch operations as above: bit for bit.  The C recursion
-    # forms them in k_cheb_init (unfused multiply-add; torch may contract its complex product), so its psi_t can start an
-    # ulp away and is compared to 1e-15 absolute (|psi_t| <= 1); the pairing itself is what the exact comparison pins.
-    assert np.array_equal(got_sharded, want)
+    # the C recursion forms the first two terms in k_cheb_init (unfused multiply-add; torch may contract its complex
+    # product), so psi_t can start an ulp away from the torch expression above: 1e-15 absolute (|psi_t| <= 1) ...
     assert np.abs(got - want).max() <= 1e-15
+    # ... and EXACTLY equal when the one-term-per-pass loop starts from the recursion's own first two terms: this is what
+    # pins the pairing (RECUR + CHEB2 epilogues) to the bits of one accumulation per term
+    acc2 = torch.from_numpy(pkg.chebyshev_time_evolve(psi0, dt, pkg.apply_H, m, cheb_n=min(cheb_n, 2), Ebounds=Eb)).cuda()
+    prev = torch.from_numpy(psi0).cuda()
+    cur, nxt = torch.empty_like(prev), torch.empty_like(prev)
+    pkg.apply_rescaled_H(cur, prev, pkg.apply_H, m, a, b)
+    for k in range(2, cheb_n):
+        pkg.cheb_step(nxt, cur, prev, acc2, m, a, b, complex(c[k]))
+        prev, cur, nxt = cur, nxt, prev
+    assert np.array_equal(got, acc2.cpu().numpy())
+    # the sharded driver (one rank) runs the same C recursion through sd_chebyshev_evolve_sharded
+    assert np.array_equal(got_sharded, got)
 
 
 def test_chebyshev_evolve_device_resident(pkg):

@@ -214,3 +214,29 @@ def test_sharded_drivers_three_processes_one_gpu():
                        cwd=root, capture_output=True, text=True, timeout=400)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert r.stdout.count("sharded == single: True") == 6
+
+
+def test_rccl_communicator_selftest_one_rank(pkg):
+    """sd_comm_rccl_create on this one GPU (nranks = 1): librccl is found at run time, ncclCommInitRank succeeds, and the
+    entry points the sharded recursions use (ncclAllReduce on the compute stream, grouped ncclSend/ncclRecv on the
+    communication stream fenced by events) move the right bytes.  What needs peers is covered by the gloo rehearsals."""
+    import ctypes as C
+    import torch
+    ctx = pkg.default_context()
+    idbuf = (C.c_ubyte * 128)()
+    pkg.check(pkg.lib().sd_comm_rccl_unique_id(idbuf))
+    h = C.c_void_p()
+    pkg.check(pkg.lib().sd_comm_rccl_create(ctx.h, 0, 1, idbuf, C.byref(h)), ctx.h)
+    try:
+        pkg.check(pkg.lib().sd_comm_selftest(ctx.h, h), ctx.h)
+        # a one-rank communicator with an unsharded model: the sharded entry points reduce to the single-GPU recursion
+        m = pkg.XXZChain(14, nup=7)
+        psi = torch.randn(m.N, dtype=torch.complex128, device="cuda")
+        out, out2 = torch.empty_like(psi), torch.empty_like(psi)
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        pkg.check(pkg.lib().sd_apply_sharded(ctx.h, m.h, h, 2, out.data_ptr(), psi.data_ptr(), m.N, 1), ctx.h)
+        pkg.check(pkg.lib().sd_apply_dev(ctx.h, m.h, 2, out2.data_ptr(), psi.data_ptr(), m.N), ctx.h)
+        torch.cuda.synchronize()
+        assert torch.equal(out, out2)
+    finally:
+        pkg.lib().sd_comm_destroy(h)
