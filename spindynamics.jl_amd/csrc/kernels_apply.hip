@@ -211,24 +211,52 @@ __global__ __launch_bounds__(BLOCK, 4) void k_apply_tiled(sd_dev_model dm, doubl
   SD_STAMP(3);
   SD_STAMP(4);
 
-  // ---- first general bond (e.g. the periodic (L,1) bond): its gathers are requested now, into the idle stream registers,
-  // so that their latency hides behind the suffix phase; they are accumulated in their turn, after the suffix bonds ----
-  const uint64_t pmask = ((uint64_t)1 << p) - 1;
+  // ---- general bonds (anything after the leading chain bonds: the periodic (L,1) bond, long-range lists) ----
+  // Where the partner row lives follows from where the two sites are (wave-uniform per bond):
+  //   both in the prefix : the whole tile maps onto tile P ^ bits at the same row offset (a coalesced stream, like a chain bond);
+  //   both in the suffix : the partner row is in this tile -- an LDS read at suf_rank[sigma ^ bits];
+  //   one in each        : every partner row is in the ONE tile P ^ prefix bit (its base is fetched once per wave), at row
+  //                        suf_rank[sigma ^ suffix bit]; the suffix sector changes with the prefix filling.
+  // The value for rows without the hop is never used.
+  struct GBond { int64_t base; uint32_t smask; int pb; int kind; };     // kind 0 prefix-prefix, 1 suffix-suffix, 2 mixed, -1 nothing to do
+  auto gbond = [&](int h) {
+    GBond g{0, 0u, 0, -1};
+    const int bi = dm.hop_i[h] - 1, bj = dm.hop_j[h] - 1;
+    const bool ip = bi < p, jp = bj < p;
+    if (ip && jp) {
+      if (((P >> bi) ^ (P >> bj)) & 1u) { g.kind = 0; g.base = dm.addr[P ^ (1u << bi) ^ (1u << bj)]; }
+    } else if (!ip && !jp) {
+      g.kind = 1; g.smask = (1u << (bi - p)) | (1u << (bj - p));
+    } else {
+      g.pb = ip ? bi : bj;
+      g.smask = 1u << ((ip ? bj : bi) - p);
+      const uint32_t Q = P ^ (1u << g.pb);
+      const int t2q = dm.nup - __popc(Q);
+      if (t2q >= 0 && t2q <= LS) { g.kind = 2; g.base = dm.addr[Q]; }
+    }
+    return g;
+  };
+  auto gflip = [&](const GBond &g, int r) -> bool {       // does row r have this hop?
+    if (g.kind == 0) return true;
+    if (g.kind == 1) return __popc(sig[r] & g.smask) == 1;
+    if (g.kind == 2) return ((P >> g.pb) & 1u) != ((sig[r] & g.smask) ? 1u : 0u);
+    return false;
+  };
+  auto gvalue = [&](const GBond &g, int r) -> V {         // psi at the partner row of row r (call only when gflip)
+    if (g.kind == 1) return tile[dm.suf_rank[sig[r] ^ g.smask]];
+    const int64_t idx = g.base + (g.kind == 0 ? (int64_t)irow[r] : (int64_t)dm.suf_rank[sig[r] ^ g.smask]);
+    return (halo && idx >= dm.n_local) ? halo[idx - dm.n_local] : psi[idx];
+  };
+  // the first general bond's values are requested now, into the idle stream registers, so that their latency hides behind
+  // the suffix phase; they are accumulated in their turn, after the suffix bonds
   const bool have_g = nn < dm.n_hop;
   double gJ = 0.0;
+  GBond g0{0, 0u, 0, -1};
   if (have_g) {
-    const int bi = dm.hop_i[nn] - 1, bj = dm.hop_j[nn] - 1;
+    g0 = gbond(nn);
     gJ = dm.hop_J[nn];
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const uint64_t s = (uint64_t)P | ((uint64_t)sig[r] << p);
-      va[r] = V{};
-      if (((s >> bi) ^ (s >> bj)) & 1) {
-        const uint64_t s2 = s ^ ((uint64_t)1 << bi) ^ ((uint64_t)1 << bj);
-        const int64_t idx = dm.addr[(uint32_t)(s2 & pmask)] + dm.suf_rank[(uint32_t)(s2 >> p)];
-        va[r] = (halo && idx >= dm.n_local) ? halo[idx - dm.n_local] : psi[idx];
-      }
-    }
+    for (int r = 0; r < R; ++r) va[r] = (tid + r * BLOCK < len && gflip(g0, r)) ? gvalue(g0, r) : V{};
   }
   // ---- 4. bonds inside the suffix: LDS reads at idx +- C(LS-a-1, u); branch-free so the R rows' reads overlap ----
   if (nn > 0 && !(DIAG && (dm.dbg & 4))) {
@@ -253,26 +281,18 @@ __global__ __launch_bounds__(BLOCK, 4) void k_apply_tiled(sd_dev_model dm, doubl
       for (int r = 0; r < R; ++r) acc[r] = accum<FMA>(acc[r], J, v[r]);
     }
   }
-  // ---- remaining (general) bonds: rank through the tile tables ----
+  // ---- the general bonds in list order ----
   if (have_g) {
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const uint64_t s = (uint64_t)P | ((uint64_t)sig[r] << p);
-      const int bi = dm.hop_i[nn] - 1, bj = dm.hop_j[nn] - 1;
-      if (((s >> bi) ^ (s >> bj)) & 1) acc[r] = accum<false>(acc[r], gJ, va[r]);   // rows without the hop keep acc untouched
-    }
+    for (int r = 0; r < R; ++r)
+      if (gflip(g0, r)) acc[r] = accum<false>(acc[r], gJ, va[r]);   // rows without the hop keep acc untouched
     for (int h = nn + 1; h < dm.n_hop; ++h) {
-      const int bi = dm.hop_i[h] - 1, bj = dm.hop_j[h] - 1;
+      const GBond g = gbond(h);
+      if (g.kind < 0) continue;
       const double J = dm.hop_J[h];
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const uint64_t s = (uint64_t)P | ((uint64_t)sig[r] << p);
-        if (((s >> bi) ^ (s >> bj)) & 1) {
-          const uint64_t s2 = s ^ ((uint64_t)1 << bi) ^ ((uint64_t)1 << bj);
-          const int64_t idx = dm.addr[(uint32_t)(s2 & pmask)] + dm.suf_rank[(uint32_t)(s2 >> p)];
-          acc[r] = accum<false>(acc[r], J, (halo && idx >= dm.n_local) ? halo[idx - dm.n_local] : psi[idx]);
-        }
-      }
+      for (int r = 0; r < R; ++r)
+        if (tid + r * BLOCK < len && gflip(g, r)) acc[r] = accum<false>(acc[r], J, gvalue(g, r));
     }
   }
 
@@ -544,11 +564,16 @@ int launch_tiled(sd_ctx *ctx, const sd_dev_model &dm, int nt, int cls, size_t sh
 }  // namespace
 
 int sd_launch_apply(sd_ctx *ctx, const sd_model *m, int dtype, void *out, const void *psi, int epi,
-                    const sd_epi_args &ea, int part) {
+                    const sd_epi_args &ea_in, int part) {
   if (!m->dev_ready) return sd_set_err(ctx, SD_EARG, "model has no device tables (created without a context)");
   if (dtype != SD_F64 && dtype != SD_C128) return sd_set_err(ctx, SD_EARG, "dtype must be SD_F64 or SD_C128");
   const bool sums = (epi == SD_EPI_DOT || epi == SD_EPI_KPM || epi == SD_EPI_RESCALE_DOT);
   sd_dev_model dm = m->dm;
+  sd_epi_args ea = ea_in;
+  {
+    static const int hint = getenv("SD_STREAM_HINT") ? atoi(getenv("SD_STREAM_HINT")) : 3;   // measured best: device_common.hpp, "Streams of the epilogues"
+    ea.stream_hint = hint;
+  }
   if (dm.n_local == 0) {      // a rank without rows still takes part in the reductions: its sums are zero
     if (sums) SD_HIP(ctx, hipMemsetAsync(ea.sums_dst ? ea.sums_dst : ctx->d_scalars, 0, 2 * sizeof(double), ctx->stream));
     return SD_OK;

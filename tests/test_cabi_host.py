@@ -27,6 +27,53 @@ def test_library_exports_every_declared_symbol(pkg):
     assert set(pkg.PROTOTYPES) == set(names)
 
 
+def header_prototypes():
+    """name -> (return kind, [parameter kinds]) parsed from include/spindyn.h; kinds: int, i64, u64, double, ptr, void"""
+    src = open(os.path.join(ROOT, "include", "spindyn.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r"typedef struct sd_comm_callbacks \{.*?\} sd_comm_callbacks;", "", src, flags=re.S)   # function-pointer members
+
+    def kind(t):
+        t = t.strip()
+        if "*" in t or "[" in t:
+            return "ptr"
+        t = re.sub(r"\b(const|unsigned)\b", "", t).split()
+        base = t[0] if t else "void"
+        return {"int": "int", "int64_t": "i64", "uint64_t": "u64", "double": "double", "void": "void"}[base]
+
+    out = {}
+    for ret, name, params in re.findall(r"([A-Za-z_][A-Za-z0-9_ ]*?[ \*]+)(sd_[A-Za-z0-9_]+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S):
+        ps = [] if params.strip() in ("", "void") else [kind(x) for x in params.split(",")]
+        out[name] = (kind(ret), ps)
+    return out
+
+
+def test_ctypes_prototypes_match_the_header_argument_by_argument(pkg):
+    """The Python mirror's ctypes table against the C declarations: same number of parameters, and each of the same kind
+    (int / int64 / uint64 / double / pointer) -- a drifted signature must not pass (tests/cabi_consumer.c pins the
+    types of the calls it makes with the C compiler; this covers every entry point)."""
+    protos = header_prototypes()
+    assert set(protos) == set(pkg.PROTOTYPES)
+
+    def ckind(t):
+        if t is None:
+            return "void"
+        if t is C.c_int:
+            return "int"
+        if t is C.c_int64:
+            return "i64"
+        if t is C.c_uint64:
+            return "u64"
+        if t is C.c_double:
+            return "double"
+        return "ptr"            # c_void_p, c_char_p, POINTER(...), function pointers
+
+    for name, (res, args) in pkg.PROTOTYPES.items():
+        hret, hargs = protos[name]
+        assert ckind(res) == hret, (name, "return", ckind(res), hret)
+        assert [ckind(a) for a in args] == hargs, (name, [ckind(a) for a in args], hargs)
+
+
 def test_no_cpu_fallback(pkg):
     l = pkg.lib()
     if l.sd_device_count() > 0:
