@@ -237,11 +237,48 @@ int sd_build_plan(sd_model *m, int rank, int nranks, std::string &err) {
   int p = L - LS;
   if (m->nup < 0 || p > SD_MAX_PREFIX_BITS) {
     // generic (untiled) path: per-row rank/unrank on device
-    if (nranks != 1) { err = "sharding needs a fixed-nup sector with at most 2^26 prefix tiles"; return SD_EARG; }
     m->p = -1; m->LS = 0;
     m->row_lo = 0; m->row_hi = m->N; m->n_local = m->N;
+    m->shard_mode = 0; m->n_interior = 0; m->fs_dbits = 0;
+    m->pack_src.clear(); m->pack_dst.clear(); m->pack_len.clear(); m->n_send = 0;
     // full 2^L basis: idx = state, so 2^10 consecutive rows form a tile without any table (k_apply_fulltile)
     m->full_ls = (m->nup < 0 && L >= 12 && L <= 40 && !getenv("SD_NO_FULLTILE")) ? 10 : 0;
+    if (nranks == 1) return SD_OK;
+    // Full basis over 2^d ranks (src/Hamiltonian.jl:223,255-257: idx = state): the rank is the top d index bits, i.e. the
+    // configuration of sites L-d+1..L; a rank owns the contiguous rows [r N/P, (r+1) N/P).  Chain bonds below site L-d stay
+    // inside a rank.  The bond (L-d, L-d+1) straddles the cut: the rows whose site L-d differs from the rank's lowest bit
+    // read, from rank r^1, the contiguous HALF of its vector whose site L-d equals this rank's lowest bit.  A bond between
+    // two rank bits that differ maps the whole vector onto the whole vector of rank r ^ (3 << k), at the same offset.
+    int d = 0;
+    while ((1 << d) < nranks) ++d;
+    const int nnh = count_nn_hops(m);
+    if (m->nup >= 0) { err = "sharding needs a fixed-nup sector with at most 2^26 prefix tiles, or the full basis"; return SD_EARG; }
+    if ((1 << d) != nranks || nranks > SD_FS_MAX_RANKS) { err = "the full 2^L basis shards over 2, 4 or 8 ranks (top index bits)"; return SD_EARG; }
+    if (m->full_ls == 0 || L - d < m->full_ls + 1) { err = "full-basis sharding needs L >= 12 and at least two tiles per rank"; return SD_EARG; }
+    if (nnh == 0 || (int)m->hop_i.size() != nnh) { err = "full-basis sharding needs the open chain's hop list (bonds (i, i+1) in order)"; return SD_EARG; }
+    m->fs_dbits = d;
+    m->n_local = m->N / nranks;
+    m->row_lo = (int64_t)rank * m->n_local; m->row_hi = m->row_lo + m->n_local;
+    for (int q = 0; q < SD_FS_MAX_RANKS; ++q) { m->fs_halo_off[q] = -1; m->fs_peer_lo[q] = 0; }
+    int64_t hoff = 0;
+    auto add_pair = [&](int me, int peer, int64_t peer_lo, int64_t count, bool recv) {
+      if (recv) {
+        m->fs_halo_off[peer] = hoff; m->fs_peer_lo[peer] = peer_lo;
+        m->recv_slabs.push_back({peer, m->n_local + hoff, count, (int64_t)peer * m->n_local + peer_lo});
+        hoff += count;
+      } else {
+        m->send_slabs.push_back({peer, peer_lo, count, (int64_t)me * m->n_local + peer_lo});
+      }
+    };
+    // what this rank receives, in a fixed order (straddling bond first, then the bonds between rank bits, ascending)
+    add_pair(rank, rank ^ 1, (int64_t)(rank & 1) * (m->n_local / 2), m->n_local / 2, true);
+    for (int k = 0; k + 1 < d; ++k)
+      if (((rank >> k) ^ (rank >> (k + 1))) & 1) add_pair(rank, rank ^ (3 << k), 0, m->n_local, true);
+    // what the peers receive from this rank: the same rule seen from their side, in THEIR order (slab k of a pair pairs up)
+    add_pair(rank, rank ^ 1, (int64_t)((rank ^ 1) & 1) * (m->n_local / 2), m->n_local / 2, false);
+    for (int k = 0; k + 1 < d; ++k)
+      if (((rank >> k) ^ (rank >> (k + 1))) & 1) add_pair(rank, rank ^ (3 << k), 0, m->n_local, false);
+    m->n_halo = hoff;
     return SD_OK;
   }
   m->p = p; m->LS = LS; m->full_ls = 0;
@@ -523,6 +560,8 @@ int sd_upload_model(sd_model *m, std::string &err) {
   d.n_hop = (int)m->hop_i.size(); d.n_zz = (int)m->zz_i.size();
   d.N = m->N; d.n_local = m->n_local; d.row_lo = m->row_lo;
   d.full_ls = m->full_ls;
+  d.fs_dbits = m->fs_dbits;
+  for (int q = 0; q < SD_FS_MAX_RANKS; ++q) { d.fs_halo_off[q] = m->fs_halo_off[q]; d.fs_peer_lo[q] = m->fs_peer_lo[q]; }
   d.nn_hops = (m->p >= 0 || m->full_ls > 0) ? count_nn_hops(m) : 0;
   d.field_zero = 1;
   for (double h : m->field) if (h != 0.0) d.field_zero = 0;

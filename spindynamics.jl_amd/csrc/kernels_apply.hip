@@ -337,6 +337,7 @@ __global__ __launch_bounds__(256, 4) void k_apply_fulltile(sd_dev_model dm, doub
   V *tile = reinterpret_cast<V *>(smem);               // TL rows + one all-zero row at index TL
   double *red = reinterpret_cast<double *>(smem + (size_t)(TL + 1) * sizeof(V));
   const V *__restrict__ psi = reinterpret_cast<const V *>(psi_);
+  const V *__restrict__ halo = reinterpret_cast<const V *>(ea.halo);
   const int tid = threadIdx.x, lane = tid & 63;
   // blocks are dealt round-robin to the 8 XCDs: hand each XCD runs of 32 consecutive tiles (neighbouring tiles are partners)
   uint32_t T = blockIdx.x;
@@ -344,7 +345,10 @@ __global__ __launch_bounds__(256, 4) void k_apply_fulltile(sd_dev_model dm, doub
     const uint32_t x = T & 7u, j = T >> 3, g = j >> 5, i = j & 31u;
     T = (g << 8) + (x << 5) + i;
   }
-  const int64_t base = (int64_t)T << LF;
+  const int64_t base = (int64_t)T << LF;                       // local row of the tile's first row
+  // sharded by the top index bits: this rank's tiles are the global tiles T + row_lo / 2^LF (the rank is their top bits)
+  const uint32_t Tg = T + (uint32_t)(dm.row_lo >> LF);
+  const int64_t gbase = (int64_t)Tg << LF;                     // its state (= global row)
   const int nn = dm.nn_hops;
 
   V own[R];
@@ -370,8 +374,20 @@ __global__ __launch_bounds__(256, 4) void k_apply_fulltile(sd_dev_model dm, doub
         fl = true;
       } else {
         const int b = a - LF - 1;
-        fl = ((T >> b) ^ (T >> (b + 1))) & 1u;
-        my_base = (int64_t)(T ^ (3u << b)) << LF;
+        fl = ((Tg >> b) ^ (Tg >> (b + 1))) & 1u;
+        // partner tile: in this rank's rows, or (a bond that reaches into the rank bits) in the slab imported from rank q
+        const uint32_t Tp = Tg ^ (3u << b);
+        const int tb = dm.L - LF - dm.fs_dbits;                  // tile-index bits below the rank bits
+        const uint32_t q = Tp >> tb;
+        const int64_t at_peer = (int64_t)(Tp & ((1u << tb) - 1u)) << LF;
+        my_base = at_peer;
+        if (q != (Tg >> tb)) {
+          int64_t ho = 0, plo = 0;
+#pragma unroll
+          for (int q2 = 0; q2 < SD_FS_MAX_RANKS; ++q2)
+            if ((uint32_t)q2 == q) { ho = dm.fs_halo_off[q2]; plo = dm.fs_peer_lo[q2]; }
+          my_base = dm.n_local + ho + at_peer - plo;
+        }
       }
       my_J = dm.hop_J[a - 1];
     }
@@ -384,7 +400,8 @@ __global__ __launch_bounds__(256, 4) void k_apply_fulltile(sd_dev_model dm, doub
     return fb;
   };
   auto issue = [&](const FarBond &fb, V(&v)[R]) {
-    const __amdgpu_buffer_rsrc_t rs = make_rsrc(psi + fb.base, (uint32_t)fb.n * ES);
+    const V *__restrict__ pb = (halo && fb.base >= dm.n_local) ? halo + (fb.base - dm.n_local) : psi + fb.base;
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(pb, (uint32_t)fb.n * ES);
     const uint32_t lo_b = (uint32_t)fb.lo * ES;
 #pragma unroll
     for (int r = 0; r < R; ++r) buf_load(v[r], rs, ioff[r] - lo_b);
@@ -399,7 +416,7 @@ __global__ __launch_bounds__(256, 4) void k_apply_fulltile(sd_dev_model dm, doub
   V acc[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    acc[r] = vscale(diag_of(dm, (uint64_t)base + (uint64_t)(tid + r * BLOCK)), own[r]);
+    acc[r] = vscale(diag_of(dm, (uint64_t)gbase + (uint64_t)(tid + r * BLOCK)), own[r]);
     tile[tid + r * BLOCK] = own[r];
   }
   if (tid == 0) tile[TL] = V{};
@@ -437,7 +454,7 @@ __global__ __launch_bounds__(256, 4) void k_apply_fulltile(sd_dev_model dm, doub
     const double J = dm.hop_J[h];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const uint64_t s = (uint64_t)base + (uint64_t)(tid + r * BLOCK);
+      const uint64_t s = (uint64_t)gbase + (uint64_t)(tid + r * BLOCK);       // (sharded plans carry chain bonds only)
       if (((s >> bi) ^ (s >> bj)) & 1) acc[r] = accum<false>(acc[r], J, psi[s ^ ((uint64_t)1 << bi) ^ ((uint64_t)1 << bj)]);
     }
   }
@@ -622,7 +639,9 @@ int sd_launch_apply(sd_ctx *ctx, const sd_model *m, int dtype, void *out, const 
       if (rc2) return rc2;
     }
   } else if (m->full_ls > 0) {
-    const int64_t nb = dm.N >> m->full_ls;
+    // sharded by the top index bits: every tile may read the halo, so there is no interior part (part 1 launches nothing)
+    if (part == 1) return SD_OK;
+    const int64_t nb = dm.n_local >> m->full_ls;
     if (sums) { int rc = sd_ensure_partials(ctx, 2 * (size_t)nb + 2 * SD_RED_STAGE_BLOCKS); if (rc) return rc; }
     const size_t esz = dtype == SD_C128 ? 16 : 8;
     const size_t shmem = (((size_t)1 << m->full_ls) + 1) * esz + 32 * sizeof(double) + 16;

@@ -52,8 +52,8 @@ __global__ __launch_bounds__(256) void k_szq_generic(sd_dev_model dm, SzqPhases 
                                                      const double *__restrict__ psi0, double2 *__restrict__ phi) {
   const bool full = dm.nup < 0;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < dm.N; idx += stride) {
-    const uint64_t s = full ? (uint64_t)idx : unrank_g(dm, idx);
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < dm.n_local; idx += stride) {
+    const uint64_t s = full ? (uint64_t)(dm.row_lo + idx) : unrank_g(dm, idx);     // full basis: state = global row
     szq_row<NCIN>(dm, ph, normfact, s, psi0, idx, phi);
   }
 }
@@ -109,8 +109,8 @@ __global__ __launch_bounds__(256) void k_obs(sd_dev_model dm, const double *__re
   } else {
     const bool full = dm.nup < 0;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < dm.N; idx += stride)
-      obs_row<NC, MODE>(dm, full ? (uint64_t)idx : unrank_g(dm, idx), psi, idx, c0, cn, acc);
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < dm.n_local; idx += stride)
+      obs_row<NC, MODE>(dm, full ? (uint64_t)(dm.row_lo + idx) : unrank_g(dm, idx), psi, idx, c0, cn, acc);
   }
 #pragma unroll
   for (int k = 0; k < SD_OBS_CHUNK; k += 2) {
@@ -201,7 +201,7 @@ int sd_launch_observable(sd_ctx *ctx, const sd_model *m, int dtype, const void *
   if (!m->dev_ready) return sd_set_err(ctx, SD_EARG, "model has no device tables (created without a context)");
   if (dtype != SD_F64 && dtype != SD_C128) return sd_set_err(ctx, SD_EARG, "dtype must be SD_F64 or SD_C128");
   const sd_dev_model &dm = m->dm;
-  int nb = m->p >= 0 ? std::min(dm.n_tiles, 2048) : (int)std::min<int64_t>(2048, (dm.N + 255) / 256);
+  int nb = m->p >= 0 ? std::min(dm.n_tiles, 2048) : (int)std::min<int64_t>(2048, (dm.n_local + 255) / 256);
   if (nb < 1) nb = 1;
   int rc = sd_ensure_partials(ctx, (size_t)nb * SD_OBS_CHUNK);
   if (rc) return rc;
@@ -239,7 +239,7 @@ int sd_launch_fill_randn_local(sd_ctx *ctx, const sd_model *m, int dtype, void *
   if (!m->dev_ready) return sd_set_err(ctx, SD_EARG, "model has no device tables (created without a context)");
   const sd_dev_model &dm = m->dm;
   const int per = dtype == SD_C128 ? 2 : 1;
-  if (m->p < 0) return sd_k_fill_randn(ctx, (double *)x, dm.N * per, seed, 0);
+  if (m->p < 0) return sd_k_fill_randn(ctx, (double *)x, dm.n_local * per, seed, (uint64_t)(dm.row_lo * per));   // keyed by the global element index
   if (dm.n_tiles == 0) return SD_OK;
   hipLaunchKernelGGL(k_fill_randn_tiles, dim3(std::min(dm.n_tiles, 8192)), dim3(256), 0, ctx->stream, dm, (double *)x, per, seed);
   SD_HIP(ctx, hipGetLastError());
@@ -249,6 +249,7 @@ int sd_launch_fill_randn_local(sd_ctx *ctx, const sd_model *m, int dtype, void *
 int sd_launch_spin_op(sd_ctx *ctx, const sd_model *m, int dtype, int site, int op, const void *psi, void *out) {
   if (!m->dev_ready) return sd_set_err(ctx, SD_EARG, "model has no device tables (created without a context)");
   const sd_dev_model &dm = m->dm;
+  if (m->nranks > 1 && m->p < 0) return sd_set_err(ctx, SD_EARG, "spin operators act on an unsharded full basis (the flipped row may live on another rank)");
   int64_t nb = (dm.N + 255) / 256;
   if (nb > 16384) nb = 16384;
   if (nb < 1) nb = 1;
@@ -275,7 +276,7 @@ int sd_launch_szq(sd_ctx *ctx, const sd_model *m, int dtype_in, const void *psi0
       hipLaunchKernelGGL(k_szq_tiled<1>, dim3(dm.n_tiles), dim3(256), 0, ctx->stream, dm, ph, normfact,
                          (const double *)psi0, (double2 *)phi);
   } else {
-    int64_t nb = (dm.N + 255) / 256;
+    int64_t nb = (dm.n_local + 255) / 256;
     if (nb > 8192) nb = 8192;
     if (dtype_in == SD_C128)
       hipLaunchKernelGGL(k_szq_generic<2>, dim3((unsigned)nb), dim3(256), 0, ctx->stream, dm, ph, normfact,

@@ -800,15 +800,19 @@ static int kpm_sqw_core(Op &op, int dtype, const void *psi0, bool on_dev, int64_
   if (kpm_m < 2) return sd_set_err(ctx, SD_EARG, "kpm_m must be >= 2");
   if (!psi0 || !Smat || (Qn > 0 && !q) || (W > 0 && !omega)) return sd_set_err(ctx, SD_EARG, "null argument");
   const int nc = dtype == SD_C128 ? 2 : 1;
-  DBuf in, psic, tmp, phi;
-  RC(psic.alloc(ctx, 2 * n)); RC(tmp.alloc(ctx, 2 * n)); RC(phi.alloc(ctx, 2 * n));
+  DBuf in, psic, phi;
+  RC(psic.alloc(ctx, 2 * n)); RC(phi.alloc(ctx, 2 * n));
   const double *inp = (const double *)psi0;
   if (!on_dev) { RC(in.alloc(ctx, nc * n)); RC(h2d(ctx, in.p, psi0, nc * n)); inp = in.p; }
   RC(sd_k_promote(ctx, psic.p, inp, nc, n));                                              // :202
+  in.release();
   sd_epi_args ea;
-  RC(op.apply(SD_C128, tmp.p, psic.p, SD_EPI_DOT, ea));                                   // :208-209
+  double s[2];
+  // phi doubles as the scratch for H psi0 (only <psi0|H psi0> is kept): the recursion then holds psi0, phi and its three
+  // work vectors -- five vectors of n elements plus halo and send buffer on a shard
+  RC(op.apply(SD_C128, phi.p, psic.p, SD_EPI_DOT, ea));                                   // :208-209
   RC(op.reduce(ctx->d_scalars + 0, 2));
-  double s[2]; RC(sd_read_scalars(ctx, 0, 2, s));
+  RC(sd_read_scalars(ctx, 0, 2, s));
   const double E0 = s[0];
   if (!have_ab) {                                                                         // :212-214
     double Emin, Emax;

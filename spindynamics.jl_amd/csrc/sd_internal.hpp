@@ -30,6 +30,7 @@
 #define SD_MAX_L 63
 #define SD_MAX_BONDS 4096  // bond lists are uploaded to device memory; this bounds host validation only
 #define SD_MAX_PREFIX_BITS 26
+#define SD_FS_MAX_RANKS 8   // full-basis sharding: ranks = top index bits, nranks in {2, 4, 8}
 
 // everything a workgroup needs to start on a tile, fetched with one scalar load
 struct sd_tile_rec {
@@ -66,6 +67,9 @@ struct sd_dev_model {
   int p, LS;             // prefix / suffix site counts (tiled path); p = -1 when untiled
   int n_hop, n_zz;
   int full_ls;           // full 2^L basis, tiled path: a tile is 2^full_ls consecutive rows (0: not in use)
+  int fs_dbits;          // full basis sharded by its top fs_dbits index bits (0: unsharded); rank = those bits
+  int64_t fs_halo_off[SD_FS_MAX_RANKS];   // per peer rank: element offset of its slab in the halo buffer, -1: nothing imported from it
+  int64_t fs_peer_lo[SD_FS_MAX_RANKS];    // per peer rank: first row (of the peer's local vector) held by that slab
   int nn_hops;           // leading hops that are exactly (1,2),(2,3),...,(L-1,L) in order (L-1 or 0)
   int diag_mode;         // 0 list order with exact term magnitudes (select + add per term), 1 uniform closed form, 2 literal reference loop (SD_DIAG_LITERAL)
   double diag_q;         // Jz/4 for diag_mode 1
@@ -116,7 +120,10 @@ struct sd_model {
   std::vector<int64_t> binom;  // host copy
   // plan
   int p = -1, LS = 0;
-  int full_ls = 0;             // full-basis tiled path (nup < 0, L >= 12, unsharded): log2 rows per tile
+  int full_ls = 0;             // full-basis tiled path (nup < 0, L >= 12): log2 rows per tile
+  int fs_dbits = 0;            // full basis sharded by its top fs_dbits index bits
+  int64_t fs_halo_off[SD_FS_MAX_RANKS] = {-1, -1, -1, -1, -1, -1, -1, -1};
+  int64_t fs_peer_lo[SD_FS_MAX_RANKS] = {0};
   int rank = 0, nranks = 1;
   int64_t row_lo = 0, row_hi = 0, n_local = 0, n_halo = 0;
   std::vector<uint32_t> tile_prefix;  // local tiles

@@ -107,6 +107,9 @@ class Model:
 
     def local_rows(self):
         """Global basis index of every local row (int64 array of n_local entries) -- for tests / import-export."""
+        info = self.shard_info()
+        if self.nup is None:          # full basis: a rank owns the contiguous rows [row_lo, row_hi) (top index bits)
+            return np.arange(int(info.row_lo), int(info.row_hi), dtype=np.int64)
         lb, gb, ln = self.local_tiles()
         out = np.empty(int(self.shard_info().n_local), np.int64)
         for a, b, c in zip(lb, gb, ln):

@@ -35,6 +35,15 @@ def test_virtual_shards_random(pkg, seed, monkeypatch):
     check_virtual_shards(pkg, L, nup, P, str(rng.choice(["range", "class"])), kw, need_interior=False)
 
 
+@pytest.mark.parametrize("L,P", [(13, 2), (14, 4), (15, 8), (16, 4), (17, 2)])
+@pytest.mark.parametrize("kw", [{}, {"Jxy": 0.7, "Jz": -0.4, "hz": 0.3}])
+def test_virtual_shards_full_basis_by_top_bits(pkg, L, P, kw):
+    """nup = nothing (src/Hamiltonian.jl:223,255-257: idx = state): the 2^L basis sharded by its top index bits.  A rank owns
+    the contiguous rows [r N/P, (r+1) N/P); the bond that straddles the cut imports the matching half of rank r^1, a bond
+    between two rank bits that differ the whole vector of rank r ^ (3 << k).  Bit-identical to the unsharded apply."""
+    check_virtual_shards(pkg, L, None, P, "range", kw, need_interior=False)
+
+
 def check_virtual_shards(pkg, L, nup, P, mode, kw, need_interior=True):
     import torch
     full = pkg.XXZChain(L, nup=nup, **kw)
