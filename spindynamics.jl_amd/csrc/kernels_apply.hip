@@ -568,6 +568,17 @@ int launch_tiled(sd_ctx *ctx, const sd_dev_model &dm, int nt, int cls, size_t sh
   // 4 rows per thread; cls selects the workgroup size (64 << cls threads) that covers the segment's longest tile
   constexpr int R = 4;
   if ((64 << cls) * R < max_len) return sd_set_err(ctx, SD_EINTERNAL, "tile longer than its workgroup can hold");
+  if constexpr (NC == 1) {
+    // Float64: 8 rows per thread in workgroups of half the size (same registers as 4 ComplexF64 rows; the per-thread
+    // set-up -- far-bond list, descriptors -- is paid once per 8 rows).  SD_F64_ROWS=4 keeps 4 rows per thread.
+    static const int rows = getenv("SD_F64_ROWS") ? atoi(getenv("SD_F64_ROWS")) : 8;   // measured at L=30: 1.80 -> 1.74 ms
+    if (rows == 8 && cls >= 1 && cls <= 3)
+      switch (cls) {
+        case 1: return launch_tiled_cfg<NC, 8, 64, FMA>(ctx, dm, nt, shmem, out, psi, epi, ea, max_len);
+        case 2: return launch_tiled_cfg<NC, 8, 128, FMA>(ctx, dm, nt, shmem, out, psi, epi, ea, max_len);
+        case 3: return launch_tiled_cfg<NC, 8, 256, FMA>(ctx, dm, nt, shmem, out, psi, epi, ea, max_len);
+      }
+  }
   switch (cls) {
     case 0: return launch_tiled_cfg<NC, R, 64, FMA>(ctx, dm, nt, shmem, out, psi, epi, ea, max_len);
     case 1: return launch_tiled_cfg<NC, R, 128, FMA>(ctx, dm, nt, shmem, out, psi, epi, ea, max_len);
