@@ -76,8 +76,9 @@ int sd_ctx_set_stream(sd_ctx *ctx, void *hip_stream);
 int sd_ctx_set_kpm_doubling(sd_ctx *ctx, int on);
 /* A context keeps between calls: the device staging buffers of the host-pointer operator calls (sd_apply,
  * sd_apply_rescaled: two vectors), its reduction scratch, and the work vectors of the recursion-level calls (a pool of at
- * most SD_POOL_MAX_GB = 96 GB by default: hipMalloc of one 9.6 GB vector at L=32 takes 0.4-0.5 s, as long as twenty
- * applies -- the role of the reference's `workspace` argument, src/TimeEvolution/Chebyshev.jl:61-66).  This call frees all
+ * most SD_POOL_MAX_GB = 96 GB by default: a hipMalloc/hipFree pair costs 0.3-0.6 ms whatever the size, as long as
+ * 15-30 recursion steps of a small system -- the role of the reference's `workspace` argument,
+ * src/TimeEvolution/Chebyshev.jl:61-66).  This call frees all
  * of them; they are re-created on demand. */
 int sd_ctx_release_scratch(sd_ctx *ctx);
 int sd_ctx_synchronize(sd_ctx *ctx);

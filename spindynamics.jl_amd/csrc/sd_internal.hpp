@@ -53,8 +53,8 @@ struct sd_ctx {
   double *d_scalars = nullptr;  // 16 doubles, device
   double *h_scalars = nullptr;  // 16 doubles, pinned host
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  // device work vectors of the recursion-level calls, kept between calls: hipMalloc of a 9.6 GB vector (L=32) takes
-  // 0.4-0.5 s, more than twenty applies, and a malloc/free pair of a few MB ~0.4 ms, more than ten small-system steps.  sd_ctx_release_scratch / sd_ctx_destroy free them.
+  // device work vectors of the recursion-level calls, kept between calls: a hipMalloc/hipFree pair costs 0.3-0.6 ms whatever
+  // the size (profiles/alloc_cost.py), more than ten small-system steps.  sd_ctx_release_scratch / sd_ctx_destroy free them.
   std::vector<std::pair<void *, size_t>> pool_free;
   void *stage[2] = {nullptr, nullptr};   // device staging of the host-pointer operator calls (sd_apply, ...), kept between calls
   size_t stage_cap[2] = {0, 0};
