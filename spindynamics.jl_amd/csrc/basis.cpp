@@ -4,6 +4,7 @@
 // no hash map are ever built for the full dimension.
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -215,6 +216,127 @@ static void xcd_order(const sd_model *m, int p, std::vector<uint32_t> &tp_io, st
   }
 }
 
+// ---- ownership by nested bisections of popcount cells (nranks = 2, 4, 8) ----
+// d nested site blocks 1..s[d] > 1..s[d-1] > .. > 1..s[1]; rank bit i says on which side of a threshold the number of up
+// spins of one of these blocks lies, longest block first, the threshold of each further block being the conditional median
+// given the sides chosen before it (every rank gets about N/nranks rows).  A boundary bond (s[i], s[i]+1) changes the count
+// of exactly one block by one, so only rows whose count sits at that block's threshold cross a cut, every cut has one
+// partner rank, and a cut costs about the probability of sitting at the threshold (~ 1/sqrt(block length)): the longer the
+// blocks the better, hence nested blocks.  Evaluated from binomials over the disjoint pieces of the blocks (no loop over
+// rows or tiles); used when it imports less than the run-of-cells cut below.
+struct BisectPlan {
+  int d = 0;
+  int s[4] = {0, 0, 0, 0};            // piece i = sites s[i]+1 .. s[i+1]; block j = sites 1..s[j]
+  int thr[3][4] = {{0}};              // thr[level][sides chosen so far]: side = (count of block d-level > thr)
+  double score = 1e300;               // worst rank's imported rows per owned row
+  double busiest = 0;                 // rows on the busiest (receiver, owner) pair
+};
+
+static int bisect_owner(const BisectPlan &bp, const int *k) {   // k[i] = up spins of piece i
+  int cum[4] = {0, 0, 0, 0};
+  for (int i = 0; i < bp.d; ++i) cum[i + 1] = cum[i] + k[i];
+  int r = 0;
+  for (int lev = 0; lev < bp.d; ++lev) r = 2 * r + (cum[bp.d - lev] > bp.thr[lev][r] ? 1 : 0);
+  return r;
+}
+
+static bool eval_bisect(const sd_model *m, BisectPlan &bp) {
+  const int d = bp.d, L = m->L, nup = m->nup, P = 1 << d;
+  int len[3] = {0, 0, 0};
+  for (int i = 0; i < d; ++i) len[i] = bp.s[i + 1] - bp.s[i];
+  const int rest = L - bp.s[d];
+  auto weight = [&](const int *k) {
+    int sum = 0; double w = 1;
+    for (int i = 0; i < d; ++i) { w *= (double)B(m, len[i], k[i]); sum += k[i]; }
+    return w * (double)B(m, rest, nup - sum);
+  };
+  auto for_cells = [&](auto &&fn) {
+    int k[3] = {0, 0, 0};
+    for (k[0] = 0; k[0] <= len[0]; ++k[0])
+      for (k[1] = 0; k[1] <= (d > 1 ? len[1] : 0); ++k[1])
+        for (k[2] = 0; k[2] <= (d > 2 ? len[2] : 0); ++k[2]) fn(k);
+  };
+  // thresholds level by level: the weighted median of the block count among the cells of each side pattern so far
+  for (int lev = 0; lev < d; ++lev)
+    for (int pre = 0; pre < (1 << lev); ++pre) {
+      const int blk = d - lev;                       // block 1..s[blk]
+      std::vector<double> hist(bp.s[blk] + 1, 0.0);
+      double tot = 0;
+      for_cells([&](const int *k) {
+        int cum[4] = {0, 0, 0, 0};
+        for (int i = 0; i < d; ++i) cum[i + 1] = cum[i] + k[i];
+        int r = 0;
+        for (int q = 0; q < lev; ++q) r = 2 * r + (cum[d - q] > bp.thr[q][r] ? 1 : 0);
+        if (r != pre) return;
+        const double w = weight(k);
+        hist[cum[blk]] += w; tot += w;
+      });
+      if (tot <= 0) return false;
+      double acc = 0, bestd = 1e300; int t = 0;
+      for (int v = 0; v < bp.s[blk]; ++v) {          // side 0 = counts <= v
+        acc += hist[v];
+        const double dd = std::fabs(acc - tot / 2);
+        if (dd < bestd) { bestd = dd; t = v; }
+      }
+      bp.thr[lev][pre] = t;
+    }
+  std::vector<double> size(P, 0.0), vol(P, 0.0), pair((size_t)P * P, 0.0);
+  for_cells([&](const int *k) {
+    int sum = 0;
+    for (int i = 0; i < d; ++i) sum += k[i];
+    const int kr = nup - sum;
+    if (kr < 0 || kr > rest) return;
+    const int me = bisect_owner(bp, k);
+    size[me] += weight(k);
+    for (int i = 0; i < d; ++i) {                   // boundary bond (s[i+1], s[i+1]+1): piece i | piece i+1 (or the rest)
+      const bool last = i == d - 1;
+      const int lr = last ? rest : len[i + 1], kright = last ? kr : k[i + 1];
+      double others = 1;
+      for (int q = 0; q < d; ++q) if (q != i && (last || q != i + 1)) others *= (double)B(m, len[q], k[q]);
+      if (!last) others *= (double)B(m, rest, kr);
+      for (int dir = 0; dir < 2; ++dir) {            // 0: (up, down) -> (down, up): k_i - 1, k_right + 1;  1: the reverse
+        const double n = dir == 0 ? (double)B(m, len[i] - 1, k[i] - 1) * (double)B(m, lr - 1, kright) * others
+                                  : (double)B(m, len[i] - 1, k[i]) * (double)B(m, lr - 1, kright - 1) * others;
+        if (n <= 0) continue;
+        int k2[3] = {k[0], k[1], k[2]};
+        k2[i] += dir == 0 ? -1 : 1;
+        if (!last) k2[i + 1] += dir == 0 ? 1 : -1;
+        const int o = bisect_owner(bp, k2);
+        if (o != me) { vol[me] += n; pair[(size_t)me * P + o] += n; }
+      }
+    }
+  });
+  double tot = 0;
+  for (int r = 0; r < P; ++r) tot += size[r];
+  bp.score = 0; bp.busiest = 0;
+  for (int r = 0; r < P; ++r) {
+    if (size[r] <= 0 || size[r] > 1.15 * tot / P) return false;
+    bp.score = std::max(bp.score, vol[r] / size[r]);
+  }
+  for (double v : pair) bp.busiest = std::max(bp.busiest, v);
+  return true;
+}
+
+static bool best_bisect_plan(const sd_model *m, int p, int nranks, BisectPlan &best) {
+  int d = 0;
+  while ((1 << d) < nranks) ++d;
+  if ((1 << d) != nranks || d < 1 || d > 3 || m->nup < 0) return false;
+  bool found = false;
+  BisectPlan bp; bp.d = d;
+  for (int s1 = 2; s1 <= p - 1; ++s1)
+    for (int s2 = (d > 1 ? s1 + 2 : s1); s2 <= (d > 1 ? p - 1 : s1); ++s2)
+      for (int s3 = (d > 2 ? s2 + 2 : s2); s3 <= (d > 2 ? p - 1 : s2); ++s3) {
+        bp.s[0] = 0; bp.s[1] = s1; bp.s[2] = s2; bp.s[3] = s3;
+        if (!eval_bisect(m, bp)) continue;
+        if (getenv("SD_SHARD_DEBUG") && atoi(getenv("SD_SHARD_DEBUG")) > 1)
+          fprintf(stderr, "[sd shard]   s=(%d,%d,%d) import %.3f busiest %.3g\n", s1, s2, s3, bp.score, bp.busiest);
+        // the worst rank's import first, then the busiest pair (xGMI is point to point)
+        if (!found || bp.score < best.score * (1 - 1e-12) ||
+            (bp.score <= best.score * (1 + 1e-12) && bp.busiest < best.busiest)) { best = bp; found = true; }
+      }
+  return found;
+}
+
 int sd_build_plan(sd_model *m, int rank, int nranks, std::string &err) {
   if (nranks < 1 || rank < 0 || rank >= nranks) { err = "bad shard rank/nranks"; return SD_EARG; }
   m->rank = rank; m->nranks = nranks;
@@ -362,7 +484,22 @@ int sd_build_plan(sd_model *m, int rank, int nranks, std::string &err) {
         for (int q = 0; q < nranks; ++q) score = std::max(score, vol[q] / size[q]);
         if (score < best) { best = score; bm1 = m1; bm2 = m2; bassign = assign; }
       }
-    if (bm1 < 0) mode = 0;
+    // nested bisections (nranks = 2, 4, 8) when they import less than the run-of-cells cut
+    BisectPlan bis;
+    const bool have_bis = !getenv("SD_SHARD_NO_BISECT") && best_bisect_plan(m, p, nranks, bis);
+    if (getenv("SD_SHARD_DEBUG"))
+      fprintf(stderr, "[sd shard] cells (m1=%d, m2=%d) worst import %.3f | bisections found=%d d=%d s=(%d,%d,%d) worst import %.3f busiest pair %.3g rows\n",
+              bm1, bm2, best, (int)have_bis, bis.d, bis.s[1], bis.s[2], bis.s[3], bis.score, bis.busiest);
+    if (have_bis && (bm1 < 0 || bis.score < best)) {
+      for (size_t k = 0; k < T; ++k) {
+        int cnt[3] = {0, 0, 0};
+        for (int i = 0; i < bis.d; ++i) {
+          const uint32_t lo = bis.s[i] == 0 ? 0u : ((1u << bis.s[i]) - 1u), hi = (1u << bis.s[i + 1]) - 1u;
+          cnt[i] = __builtin_popcount(tiles[k].P & (hi & ~lo));
+        }
+        owner[k] = bisect_owner(bis, cnt);
+      }
+    } else if (bm1 < 0) mode = 0;
     else {
       const uint32_t mA = (1u << bm1) - 1, mB = (1u << bm2) - 1;
       for (size_t k = 0; k < T; ++k)
