@@ -9,7 +9,8 @@ import __graft_entry__ as g
 
 pkg = g.load_package()
 L = int(os.environ.get("SD_AUX_L", "32"))
-m = pkg.XXZChain(L, nup=L // 2)
+FULL = os.environ.get("SD_AUX_FULL") == "1"          # full 2^L basis (nup = nothing): state = row, one row per thread
+m = pkg.XXZChain(L) if FULL else pkg.XXZChain(L, nup=L // 2)
 op = pkg.ShardedOperator(m, 0, 1)
 psi = op.empty(torch.complex128, "cuda")
 op.fill_randn(psi, 3)
@@ -29,7 +30,7 @@ def ev(fn, reps=5):
 
 
 def line(what, ms, bpr):
-    print(json.dumps({"what": what, "L": L, "N": m.N, "ms": ms, "alg_B_per_row": bpr, "GBs": bpr * m.N / ms / 1e6}), flush=True)
+    print(json.dumps({"what": what, "L": L, "basis": "full" if FULL else "sector", "N": m.N, "ms": ms, "alg_B_per_row": bpr, "GBs": bpr * m.N / ms / 1e6}), flush=True)
 
 
 line("Sz_q_vector (c128 in, c128 out)", ev(lambda: pkg.Sz_q_vector(m, psi, 0.7)), 32)

@@ -132,36 +132,23 @@ __global__ __launch_bounds__(1024) void k_reduce_to(const double *__restrict__ p
   if (threadIdx.x == 0) { dst[0] = a; dst[1] = b; }
 }
 
-enum { OP_SCALE_DIV, OP_NEG, OP_SUB_AXPBY, OP_SUB_AXPBY1, OP_SUB2, OP_SUB2_1 };
-
-// scalars of an elementwise pass taken from DEVICE memory (results of earlier reductions of the same stream), so that a
-// recursion needs no host round trip between its passes: a = *a_dev (or sqrt(*a_dev)), b = *b_dev; the resolved a is stored
-// to *store_a by one thread (that is how alpha_j / beta_j of a Lanczos run are collected for one read-back at the end)
-struct EwDev { const double *a_dev = nullptr, *b_dev = nullptr; double *store_a = nullptr; int a_sqrt = 0; };
-__device__ __forceinline__ void ew_resolve(const EwDev &d, double &a, double &b) {
-  if (d.a_dev) a = d.a_sqrt ? sqrt(*d.a_dev) : *d.a_dev;
-  if (d.b_dev) b = *d.b_dev;
-  if (d.store_a && blockIdx.x == 0 && threadIdx.x == 0) *d.store_a = a;
-}
+enum { OP_SCALE_DIV, OP_NEG, OP_SUB2, OP_SUB2_1 };
 
 template <int OP>
 __device__ __forceinline__ double ew_op(double w, double v, double u, double a, double b) {
   if (OP == OP_SCALE_DIV) return v / a;
   if (OP == OP_NEG) return -w;
-  if (OP == OP_SUB_AXPBY) return w - (a * v + b * u);
-  if (OP == OP_SUB_AXPBY1) return w - a * v;
   if (OP == OP_SUB2) return (w - a * v) - b * u;
   return w - a * v;  // OP_SUB2_1
 }
-template <int OP> struct ew_reads { static constexpr bool w = OP != OP_SCALE_DIV, v = OP != OP_NEG, u = OP == OP_SUB_AXPBY || OP == OP_SUB2; };
+template <int OP> struct ew_reads { static constexpr bool w = OP != OP_SCALE_DIV, v = OP != OP_NEG, u = OP == OP_SUB2; };
 
 // elementwise pass with 16-byte accesses (n2 = number of double2 elements); NORM accumulates |w_new|^2
 template <int OP, bool NORM>
 __global__ __launch_bounds__(BS) void k_ew2(double2 *__restrict__ w, const double2 *__restrict__ v,
                                             const double2 *__restrict__ u, int64_t n2, double a, double b,
-                                            double *__restrict__ partials, EwDev dv) {
+                                            double *__restrict__ partials) {
   __shared__ double red[32];
-  ew_resolve(dv, a, b);
   double s = 0.0, s1 = 0.0;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
@@ -181,9 +168,8 @@ __global__ __launch_bounds__(BS) void k_ew2(double2 *__restrict__ w, const doubl
 template <int OP, bool NORM>
 __global__ __launch_bounds__(BS) void k_ew(double *__restrict__ w, const double *__restrict__ v,
                                            const double *__restrict__ u, int64_t n, double a, double b,
-                                           double *__restrict__ partials, EwDev dv) {
+                                           double *__restrict__ partials) {
   __shared__ double red[32];
-  ew_resolve(dv, a, b);
   double s = 0.0, s1 = 0.0;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -197,31 +183,65 @@ __global__ __launch_bounds__(BS) void k_ew(double *__restrict__ w, const double 
   }
 }
 
-// w = (w - alpha*v) - b*u  with complex alpha (src/TimeEvolution/Krylov.jl:156-159), fused |w|^2
-__global__ __launch_bounds__(BS) void k_krylov_update(double2 *__restrict__ w, const double2 *__restrict__ v,
-                                                      const double2 *__restrict__ u, int64_t N, double ar, double ai,
-                                                      double b, int have_u, double *__restrict__ partials,
-                                                      const double *__restrict__ alpha_dev, const double *__restrict__ b_dev,
-                                                      double *__restrict__ store_alpha) {
-  __shared__ double red[32];
-  if (alpha_dev) {            // alpha (re, im) and beta_prev from device memory: no host round trip between the passes
-    ar = alpha_dev[0]; ai = alpha_dev[1];
-    if (have_u) b = *b_dev;
-    if (store_alpha && blockIdx.x == 0 && threadIdx.x == 0) { store_alpha[0] = ar; store_alpha[1] = ai; }
+// ---- Lanczos / Krylov three-term update on UN-NORMALISED vectors (one pass instead of update + normalise) ----
+// The recursions keep u_j = beta_{j-1} v_j (the un-normalised w of the step before; |u_j|^2 = n2c on the device) instead of
+// v_j, so the pass  v_{j+1} = w / beta_j  (a read and a write of the whole vector) disappears.  With t = H u_cur this kernel forms
+//   alpha = <u_cur, t> / |u_cur|^2          (= <v, H v>, the Rayleigh quotient)
+//   w     = H v - alpha v - beta v_prev     with  H v = t / b_c,  v = u_cur / b_c,  v_prev = u_prev / b_p   per element
+// (b_c = sqrt(n2c), b_p = sqrt(n2p); true divisions, so v and v_prev are the very numbers the normalising pass would have
+// stored), writes w over t and accumulates |w|^2.  form 0: w - (alpha v + beta v_prev)  (src/Lanczos.jl:58-62);
+// form 1: (w - alpha v) - beta v_prev  (src/Lanczos.jl:222-224); form 2: the same with complex alpha
+// (src/TimeEvolution/Krylov.jl:156-159).  One thread stores alpha (1 or 2 doubles) and b_c.
+struct FoldScalars { double ar, ai, bc, bp; };
+__device__ __forceinline__ FoldScalars fold_resolve(const double *dot, const double *n2c, const double *n2p, int form,
+                                                    double *store_alpha, double *store_bc, bool writer) {
+  FoldScalars f;
+  const double nc = n2c ? *n2c : 1.0;
+  f.bc = n2c ? sqrt(nc) : 1.0;
+  f.bp = n2p ? sqrt(*n2p) : 1.0;
+  f.ar = dot[0] / nc;
+  f.ai = form == 2 ? dot[1] / nc : 0.0;
+  if (writer) {
+    if (store_alpha) { store_alpha[0] = f.ar; if (form == 2) store_alpha[1] = f.ai; }
+    if (store_bc && n2c) *store_bc = f.bc;
   }
+  return f;
+}
+template <int FORM, bool HAVE_U>
+__global__ __launch_bounds__(BS) void k_lanczos_fold(double2 *__restrict__ t, const double2 *__restrict__ uc,
+                                                     const double2 *__restrict__ up, int64_t N, const double *__restrict__ dot,
+                                                     const double *__restrict__ n2c, const double *__restrict__ n2p,
+                                                     double *__restrict__ store_alpha, double *__restrict__ store_bc,
+                                                     double *__restrict__ partials) {
+  __shared__ double red[32];
+  const FoldScalars f = fold_resolve(dot, n2c, n2p, FORM, store_alpha, store_bc, blockIdx.x == 0 && threadIdx.x == 0);
   double s = 0.0, s1 = 0.0;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += stride) {
-    const double2 x = v[i];
-    double2 y = w[i];
-    y.x -= ar * x.x - ai * x.y;
-    y.y -= ar * x.y + ai * x.x;
-    if (have_u) { const double2 z = u[i]; y.x -= b * z.x; y.y -= b * z.y; }
-    w[i] = y;
-    s += y.x * y.x + y.y * y.y;
+    const double2 tt = t[i], cc = uc[i];
+    const double wx = tt.x / f.bc, wy = tt.y / f.bc, vx = cc.x / f.bc, vy = cc.y / f.bc;
+    double ux = 0.0, uy = 0.0;
+    if (HAVE_U) { const double2 pp = up[i]; ux = pp.x / f.bp; uy = pp.y / f.bp; }
+    double2 r;
+    if (FORM == 0) {
+      r.x = HAVE_U ? wx - (f.ar * vx + f.bc * ux) : wx - f.ar * vx;
+      r.y = HAVE_U ? wy - (f.ar * vy + f.bc * uy) : wy - f.ar * vy;
+    } else if (FORM == 1) {
+      r.x = wx - f.ar * vx; r.y = wy - f.ar * vy;
+      if (HAVE_U) { r.x -= f.bc * ux; r.y -= f.bc * uy; }
+    } else {
+      r.x = wx - (f.ar * vx - f.ai * vy); r.y = wy - (f.ar * vy + f.ai * vx);
+      if (HAVE_U) { r.x -= f.bc * ux; r.y -= f.bc * uy; }
+    }
+    t[i] = r;
+    s += r.x * r.x + r.y * r.y;
   }
   block_reduce2(s, s1, red);
   if (threadIdx.x == 0) { partials[2 * blockIdx.x] = s; partials[2 * blockIdx.x + 1] = 0.0; }
+}
+// the scalars of the last step alone (the recursion ends on alpha_m: no vector update behind it)
+__global__ void k_lanczos_fold_scalars(const double *dot, const double *n2c, int form, double *store_alpha, double *store_bc) {
+  (void)fold_resolve(dot, n2c, nullptr, form, store_alpha, store_bc, true);
 }
 
 // y (+)= sum_k (cr[k] + i ci[k]) * X_k, columns given by pointer, accumulated in column order with exactly the arithmetic
@@ -363,20 +383,19 @@ int sd_read_scalars(sd_ctx *ctx, int slot, int count, double *out) {
 namespace {
 // one elementwise pass; when slot >= 0 the pass also reduces |w_new|^2 into ctx->d_scalars[slot]
 template <int OP>
-int launch_ew(sd_ctx *ctx, double *w, const double *v, const double *u, int64_t n, double a, double b, int slot,
-              EwDev dv = EwDev()) {
+int launch_ew(sd_ctx *ctx, double *w, const double *v, const double *u, int64_t n, double a, double b, int slot) {
   const bool vec = (n % 2 == 0) && !((((uintptr_t)w) | ((uintptr_t)v) | ((uintptr_t)u)) & 15);
   const int64_t items = vec ? n / 2 : n;
   unsigned nb = grid_for(items);
   if (slot >= 0) {
     if (nb > RED_BLOCKS) nb = RED_BLOCKS;
     int rc = sd_ensure_partials(ctx, 2 * RED_BLOCKS); if (rc) return rc;
-    if (vec) hipLaunchKernelGGL((k_ew2<OP, true>), dim3(nb), dim3(BS), 0, ctx->stream, (double2 *)w, (const double2 *)v, (const double2 *)u, items, a, b, ctx->d_partials, dv);
-    else hipLaunchKernelGGL((k_ew<OP, true>), dim3(nb), dim3(BS), 0, ctx->stream, w, v, u, items, a, b, ctx->d_partials, dv);
+    if (vec) hipLaunchKernelGGL((k_ew2<OP, true>), dim3(nb), dim3(BS), 0, ctx->stream, (double2 *)w, (const double2 *)v, (const double2 *)u, items, a, b, ctx->d_partials);
+    else hipLaunchKernelGGL((k_ew<OP, true>), dim3(nb), dim3(BS), 0, ctx->stream, w, v, u, items, a, b, ctx->d_partials);
     hipLaunchKernelGGL(k_reduce_to, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_partials, (int)nb, ctx->d_scalars + slot);
   } else {
-    if (vec) hipLaunchKernelGGL((k_ew2<OP, false>), dim3(nb), dim3(BS), 0, ctx->stream, (double2 *)w, (const double2 *)v, (const double2 *)u, items, a, b, (double *)nullptr, dv);
-    else hipLaunchKernelGGL((k_ew<OP, false>), dim3(nb), dim3(BS), 0, ctx->stream, w, v, u, items, a, b, (double *)nullptr, dv);
+    if (vec) hipLaunchKernelGGL((k_ew2<OP, false>), dim3(nb), dim3(BS), 0, ctx->stream, (double2 *)w, (const double2 *)v, (const double2 *)u, items, a, b, (double *)nullptr);
+    else hipLaunchKernelGGL((k_ew<OP, false>), dim3(nb), dim3(BS), 0, ctx->stream, w, v, u, items, a, b, (double *)nullptr);
   }
   SD_HIP(ctx, hipGetLastError());
   return SD_OK;
@@ -389,32 +408,32 @@ int sd_k_scale_div(sd_ctx *ctx, double *y, const double *x, int64_t n, double d)
 int sd_k_sub2(sd_ctx *ctx, double *w, const double *v, const double *u, int64_t n, double a, double b) {
   return u ? launch_ew<OP_SUB2>(ctx, w, v, u, n, a, b, -1) : launch_ew<OP_SUB2_1>(ctx, w, v, nullptr, n, a, b, -1);
 }
-// fused forms: same update + |w|^2 -> d_scalars[slot]
-int sd_k_sub_axpby_nrm_devs(sd_ctx *ctx, double *w, const double *v, const double *u, int64_t n, const double *a_dev,
-                            const double *b_dev, double *store_a, int slot) {
-  // w -= a v + b u with a = *a_dev, b = *b_dev (device scalars; u / b_dev null: w -= a v); |w|^2 -> d_scalars[slot]
-  EwDev dv; dv.a_dev = a_dev; dv.b_dev = u ? b_dev : nullptr; dv.store_a = store_a;
-  return u ? launch_ew<OP_SUB_AXPBY>(ctx, w, v, u, n, 0.0, 0.0, slot, dv) : launch_ew<OP_SUB_AXPBY1>(ctx, w, v, nullptr, n, 0.0, 0.0, slot, dv);
-}
-int sd_k_sub2_nrm_devs(sd_ctx *ctx, double *w, const double *v, const double *u, int64_t n, const double *a_dev,
-                       const double *b_dev, double *store_a, int slot) {
-  // w = (w - a v) - b u with a = *a_dev, b = *b_dev (device scalars; u / b_dev null: w - a v); |w|^2 -> d_scalars[slot]
-  EwDev dv; dv.a_dev = a_dev; dv.b_dev = u ? b_dev : nullptr; dv.store_a = store_a;
-  return u ? launch_ew<OP_SUB2>(ctx, w, v, u, n, 0.0, 0.0, slot, dv) : launch_ew<OP_SUB2_1>(ctx, w, v, nullptr, n, 0.0, 0.0, slot, dv);
-}
-int sd_k_scale_div_devs(sd_ctx *ctx, double *y, const double *x, int64_t n, const double *nrm2_dev, double *store_a) {
-  // y = x / sqrt(*nrm2_dev)  (correctly rounded sqrt, as std::sqrt on the host)
-  EwDev dv; dv.a_dev = nrm2_dev; dv.a_sqrt = 1; dv.store_a = store_a;
-  return launch_ew<OP_SCALE_DIV>(ctx, y, x, nullptr, n, 1.0, 0.0, -1, dv);
-}
-int sd_k_krylov_update_nrm_devs(sd_ctx *ctx, double *w, const double *v, const double *u, int64_t N, const double *alpha_dev,
-                                const double *b_dev, double *store_alpha, int slot) {
+int sd_k_lanczos_fold(sd_ctx *ctx, double *t, const double *uc, const double *up, int64_t N, int form, const double *dot_dev,
+                      const double *n2c_dev, const double *n2p_dev, double *store_alpha, double *store_bc, double *n2_out) {
+  // see k_lanczos_fold; N complex elements; |w|^2 -> n2_out[0] (n2_out[1] = 0), a device address
   int rc = sd_ensure_partials(ctx, 2 * RED_BLOCKS); if (rc) return rc;
   unsigned nb = grid_for(N);
   if (nb > RED_BLOCKS) nb = RED_BLOCKS;
-  hipLaunchKernelGGL(k_krylov_update, dim3(nb), dim3(BS), 0, ctx->stream, (double2 *)w, (const double2 *)v, (const double2 *)u, N,
-                     0.0, 0.0, 0.0, u ? 1 : 0, ctx->d_partials, alpha_dev, b_dev, store_alpha);
-  hipLaunchKernelGGL(k_reduce_to, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_partials, (int)nb, ctx->d_scalars + slot);
+  void (*k)(double2 *, const double2 *, const double2 *, int64_t, const double *, const double *, const double *, double *, double *,
+            double *) = nullptr;
+  switch (form * 2 + (up ? 1 : 0)) {
+    case 0: k = k_lanczos_fold<0, false>; break;
+    case 1: k = k_lanczos_fold<0, true>; break;
+    case 2: k = k_lanczos_fold<1, false>; break;
+    case 3: k = k_lanczos_fold<1, true>; break;
+    case 4: k = k_lanczos_fold<2, false>; break;
+    case 5: k = k_lanczos_fold<2, true>; break;
+    default: return sd_set_err(ctx, SD_EINTERNAL, "bad Lanczos update form");
+  }
+  hipLaunchKernelGGL(k, dim3(nb), dim3(BS), 0, ctx->stream, (double2 *)t, (const double2 *)uc, (const double2 *)up, N, dot_dev,
+                     n2c_dev, n2p_dev, store_alpha, store_bc, ctx->d_partials);
+  hipLaunchKernelGGL(k_reduce_to, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_partials, (int)nb, n2_out);
+  SD_HIP(ctx, hipGetLastError());
+  return SD_OK;
+}
+int sd_k_lanczos_fold_scalars(sd_ctx *ctx, int form, const double *dot_dev, const double *n2c_dev, double *store_alpha,
+                              double *store_bc) {
+  hipLaunchKernelGGL(k_lanczos_fold_scalars, dim3(1), dim3(1), 0, ctx->stream, dot_dev, n2c_dev, form, store_alpha, store_bc);
   SD_HIP(ctx, hipGetLastError());
   return SD_OK;
 }

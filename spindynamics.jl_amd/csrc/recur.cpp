@@ -140,25 +140,30 @@ int extremal_dev(Op &op, int lanc_m, double tol, double *v_prev, int negate, dou
   double nrm = norm_dev(op, v_prev, 2 * N, &rc); RC(rc);
   RC(sd_k_scale_div(ctx, v_prev, v_prev, 2 * N, nrm));                     // :40
   // the loop is queued without host round trips (alpha_j, beta_j stay on the device, see tridiag_dev); the break on
-  // beta_j < tol (:66-70) is applied to the values read back at the end
-  DBuf ab; RC(ab.alloc(ctx, 2 * (int64_t)mm));
-  double *d_al = ab.p, *d_be = ab.p + mm;
-  SD_HIP(ctx, hipMemsetAsync(ab.p, 0, sizeof(double) * 2 * (size_t)mm, ctx->stream));
+  // beta_j < tol (:66-70) is applied to the values read back at the end.  Vectors stay un-normalised (k_lanczos_fold).
+  DBuf ab; RC(ab.alloc(ctx, 4 * (int64_t)mm + 2));
+  double *d_al = ab.p, *d_be = ab.p + mm, *d_n2 = ab.p + 2 * (int64_t)mm;      // d_n2[2j]: |w_j|^2
+  SD_HIP(ctx, hipMemsetAsync(ab.p, 0, sizeof(double) * (4 * (size_t)mm + 2), ctx->stream));
   sd_epi_args ea; ea.negate = negate;
   std::vector<double> peek;
+  double *ucur = v_prev, *uprev = v_curr, *t = w.p;
+  const double *n2c = nullptr, *n2p = nullptr;       // |ucur|^2, |uprev|^2 on the device; null: normalised
   for (int j = 1; j <= mm; ++j) {
-    RC(op.apply(SD_C128, w.p, v_prev, SD_EPI_DOT, ea));                    // :51 + :55 fused -> d_scalars[0]
+    RC(op.apply(SD_C128, t, ucur, SD_EPI_DOT, ea));                        // :51 + :55 fused -> d_scalars[0]
     RC(op.reduce(ctx->d_scalars + 0, 2));
-    RC(sd_k_sub_axpby_nrm_devs(ctx, w.p, v_prev, j == 1 ? nullptr : v_curr, 2 * N, ctx->d_scalars + 0,
-                               j == 1 ? nullptr : d_be + (j - 2), d_al + (j - 1), 2));
-    if (j < mm) {
-      std::swap(v_curr, v_prev);
-      RC(op.reduce(ctx->d_scalars + 2, 1));
-      RC(sd_k_scale_div_devs(ctx, v_prev, w.p, 2 * N, ctx->d_scalars + 2, d_be + (j - 1)));   // :65, :71
+    if (j == mm) {                                                         // alpha_m; no vector behind it
+      RC(sd_k_lanczos_fold_scalars(ctx, 0, ctx->d_scalars + 0, n2c, d_al + (j - 1), j > 1 ? d_be + (j - 2) : nullptr));
+      break;
     }
+    double *n2o = d_n2 + 2 * (int64_t)j;
+    RC(sd_k_lanczos_fold(ctx, t, ucur, j == 1 ? nullptr : uprev, N, 0, ctx->d_scalars + 0, n2c, n2p, d_al + (j - 1),
+                         j > 1 ? d_be + (j - 2) : nullptr, n2o));          // :58-65 (beta_{j-1} is filed by this pass)
+    RC(op.reduce(n2o, 1));
+    { double *old = uprev; uprev = ucur; ucur = t; t = old; }
+    n2p = n2c; n2c = n2o;
     if (j % SD_BREAK_PEEK == 0 && j < mm) {
       bool broke = false;
-      RC(peek_breakdown(ctx, d_be, j, tol, peek, &broke));
+      RC(peek_breakdown(ctx, d_be, j - 1, tol, peek, &broke));
       if (broke) break;
     }
   }
@@ -263,28 +268,33 @@ int tridiag_dev(Op &op, double *vcur /* normalised start, consumed */, int lanc_
   const int64_t n = op.n;
   const int mm = (int)std::min<int64_t>(lanc_m, op.m->N);
   DBuf wb, vp, ab;
-  RC(wb.alloc(ctx, 2 * n)); RC(vp.alloc(ctx, 2 * n)); RC(ab.alloc(ctx, 2 * (int64_t)mm));
-  double *w = wb.p, *vprev = vp.p, *d_al = ab.p, *d_be = ab.p + mm;
-  SD_HIP(ctx, hipMemsetAsync(ab.p, 0, sizeof(double) * 2 * (size_t)mm, ctx->stream));
+  RC(wb.alloc(ctx, 2 * n)); RC(vp.alloc(ctx, 2 * n)); RC(ab.alloc(ctx, 4 * (int64_t)mm + 2));
+  double *d_al = ab.p, *d_be = ab.p + mm, *d_n2 = ab.p + 2 * (int64_t)mm;      // d_n2[2j]: |w_j|^2
+  SD_HIP(ctx, hipMemsetAsync(ab.p, 0, sizeof(double) * (4 * (size_t)mm + 2), ctx->stream));
   sd_epi_args ea;
   std::vector<double> peek;
+  // the vectors stay un-normalised (u_{j+1} = w_j, |w_j|^2 on the device): the update pass divides on the fly and the
+  // normalising pass of :227/:233 disappears (k_lanczos_fold)
+  double *ucur = vcur, *uprev = vp.p, *t = wb.p;
+  const double *n2c = nullptr, *n2p = nullptr;
   for (int j = 1; j <= mm - 1; ++j) {
-    RC(op.apply(SD_C128, w, vcur, SD_EPI_DOT, ea));                                                // :218-219 -> d_scalars[0]
+    RC(op.apply(SD_C128, t, ucur, SD_EPI_DOT, ea));                                                // :218-219 -> d_scalars[0]
     RC(op.reduce(ctx->d_scalars + 0, 2));
-    RC(sd_k_sub2_nrm_devs(ctx, w, vcur, j > 1 ? vprev : nullptr, 2 * n, ctx->d_scalars + 0, j > 1 ? d_be + (j - 2) : nullptr,
-                          d_al + (j - 1), 2));                                                     // :222-224, |w|^2 -> [2]
-    std::swap(vprev, vcur);
-    RC(op.reduce(ctx->d_scalars + 2, 1));
-    RC(sd_k_scale_div_devs(ctx, vcur, w, 2 * n, ctx->d_scalars + 2, d_be + (j - 1)));              // :227, :233
+    double *n2o = d_n2 + 2 * (int64_t)j;
+    RC(sd_k_lanczos_fold(ctx, t, ucur, j > 1 ? uprev : nullptr, n, 1, ctx->d_scalars + 0, n2c, n2p, d_al + (j - 1),
+                         j > 1 ? d_be + (j - 2) : nullptr, n2o));                                  // :222-227
+    RC(op.reduce(n2o, 1));
+    { double *old = uprev; uprev = ucur; ucur = t; t = old; }
+    n2p = n2c; n2c = n2o;
     if (j % SD_BREAK_PEEK == 0 && j < mm - 1) {       // bound the work queued behind a breakdown: look at the betas so far
       bool broke = false;
-      RC(peek_breakdown(ctx, d_be, j, tol, peek, &broke));
+      RC(peek_breakdown(ctx, d_be, j - 1, tol, peek, &broke));
       if (broke) break;
     }
   }
-  RC(op.apply(SD_C128, w, vcur, SD_EPI_DOT, ea));                                                  // :237-239
+  RC(op.apply(SD_C128, t, ucur, SD_EPI_DOT, ea));                                                  // :237-239
   RC(op.reduce(ctx->d_scalars + 0, 2));
-  SD_HIP(ctx, hipMemcpyAsync(d_al + (mm - 1), ctx->d_scalars + 0, sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  RC(sd_k_lanczos_fold_scalars(ctx, 1, ctx->d_scalars + 0, n2c, d_al + (mm - 1), mm > 1 ? d_be + (mm - 2) : nullptr));
   std::vector<double> host(2 * (size_t)mm);
   SD_HIP(ctx, hipMemcpyAsync(host.data(), ab.p, sizeof(double) * 2 * (size_t)mm, hipMemcpyDeviceToHost, ctx->stream));
   SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -636,20 +646,27 @@ static int krylov_evolve_core(Op &op, int dtype, const void *psi0, int64_t n, do
   RC(sd_k_scale_div(ctx, V[0].p, V[0].p, 2 * n, norm0));                                  // :148
   // the Lanczos part is queued without host round trips (see tridiag_dev): alpha_j (complex) and beta_j stay on the device
   // and are read back once; the break on |beta_j| < 1e-14 (:162-168) is applied to the values afterwards
-  DBuf ab; RC(ab.alloc(ctx, 3 * (int64_t)kry_m));
-  double *d_al = ab.p, *d_be = ab.p + 2 * (int64_t)kry_m;          // alpha as (re, im) pairs, then beta
-  SD_HIP(ctx, hipMemsetAsync(ab.p, 0, sizeof(double) * 3 * (size_t)kry_m, ctx->stream));
+  // V[j] holds the un-normalised u_{j+1} = w_j (k_lanczos_fold): no normalising pass; the final combination divides its
+  // coefficients by beta_j instead
+  DBuf ab; RC(ab.alloc(ctx, 5 * (int64_t)kry_m + 2));
+  double *d_al = ab.p, *d_be = ab.p + 2 * (int64_t)kry_m, *d_n2 = ab.p + 3 * (int64_t)kry_m;   // alpha as (re, im) pairs, beta, |w_j|^2 at [2j]
+  SD_HIP(ctx, hipMemsetAsync(ab.p, 0, sizeof(double) * (5 * (size_t)kry_m + 2), ctx->stream));
   sd_epi_args ea;
+  const double *n2c = nullptr, *n2p = nullptr;
   for (int j = 1; j <= kry_m; ++j) {
-    RC(op.apply(SD_C128, w.p, V[j - 1].p, SD_EPI_DOT, ea));                               // :153,155 -> d_scalars[0..1]
+    double *t = w.p;
+    if (j < kry_m) { RC(V[j].alloc(ctx, 2 * n)); t = V[j].p; }
+    RC(op.apply(SD_C128, t, V[j - 1].p, SD_EPI_DOT, ea));                                 // :153,155 -> d_scalars[0..1]
     RC(op.reduce(ctx->d_scalars + 0, 2));
-    RC(sd_k_krylov_update_nrm_devs(ctx, w.p, V[j - 1].p, j > 1 ? V[j - 2].p : nullptr, n, ctx->d_scalars + 0,
-                                   j > 1 ? d_be + (j - 2) : nullptr, d_al + 2 * (j - 1), 2));   // :156-159 + :161 in one pass
-    if (j < kry_m) {
-      RC(V[j].alloc(ctx, 2 * n));
-      RC(op.reduce(ctx->d_scalars + 2, 1));
-      RC(sd_k_scale_div_devs(ctx, V[j].p, w.p, 2 * n, ctx->d_scalars + 2, d_be + (j - 1)));   // :161, :169
+    if (j == kry_m) {
+      RC(sd_k_lanczos_fold_scalars(ctx, 2, ctx->d_scalars + 0, n2c, d_al + 2 * (j - 1), j > 1 ? d_be + (j - 2) : nullptr));
+      break;
     }
+    double *n2o = d_n2 + 2 * (int64_t)j;
+    RC(sd_k_lanczos_fold(ctx, t, V[j - 1].p, j > 1 ? V[j - 2].p : nullptr, n, 2, ctx->d_scalars + 0, n2c, n2p,
+                         d_al + 2 * (j - 1), j > 1 ? d_be + (j - 2) : nullptr, n2o));      // :156-161
+    RC(op.reduce(n2o, 1));
+    n2p = n2c; n2c = n2o;
   }
   std::vector<double> hostab(3 * (size_t)kry_m);
   SD_HIP(ctx, hipMemcpyAsync(hostab.data(), ab.p, sizeof(double) * 3 * (size_t)kry_m, hipMemcpyDeviceToHost, ctx->stream));
@@ -679,6 +696,7 @@ static int krylov_evolve_core(Op &op, int dtype, const void *psi0, int64_t n, do
   {                                                                                       // :185-188, one fused pass
     std::vector<const double *> cols(m_eff);
     for (int k = 0; k < m_eff; ++k) cols[k] = V[k].p;
+    for (int k = 1; k < m_eff; ++k) { yr[k] /= beta[k - 1]; yi[k] /= beta[k - 1]; }     // V[k] = beta_k v_{k+1}
     RC(sd_k_ccombine(ctx, w.p, cols.data(), n, m_eff, yr.data(), yi.data()));
   }
   const double nn = norm_dev(op, w.p, 2 * n, &rc); RC(rc);

@@ -199,13 +199,11 @@ int sd_launch_szq(sd_ctx *ctx, const sd_model *m, int dtype_in, const void *psi0
 int sd_k_dot(sd_ctx *ctx, int nc, const double *x, const double *y, int64_t N, int slot);  // conj(x).y -> [slot]=re,[slot+1]=im
 int sd_k_dotu(sd_ctx *ctx, const double *x, const double *y, int64_t N, int slot);          // complex sum x_i*y_i, NO conjugation -> [slot]=re,[slot+1]=im
 int sd_k_nrm2sq(sd_ctx *ctx, const double *x, int64_t n, int slot);
-int sd_k_krylov_update_nrm_devs(sd_ctx *ctx, double *w, const double *v, const double *u, int64_t N, const double *alpha_dev,
-                                const double *b_dev, double *store_alpha, int slot);
-int sd_k_sub_axpby_nrm_devs(sd_ctx *ctx, double *w, const double *v, const double *u, int64_t n, const double *a_dev,
-                            const double *b_dev, double *store_a, int slot);
-int sd_k_sub2_nrm_devs(sd_ctx *ctx, double *w, const double *v, const double *u, int64_t n, const double *a_dev,
-                       const double *b_dev, double *store_a, int slot);   // scalars from device memory (no host round trip)
-int sd_k_scale_div_devs(sd_ctx *ctx, double *y, const double *x, int64_t n, const double *nrm2_dev, double *store_a);
+// three-term update on un-normalised Lanczos vectors (kernels_blas1.hip, k_lanczos_fold): t <- w, |w|^2 -> n2_out[0..1]
+int sd_k_lanczos_fold(sd_ctx *ctx, double *t, const double *uc, const double *up, int64_t N, int form, const double *dot_dev,
+                      const double *n2c_dev, const double *n2p_dev, double *store_alpha, double *store_bc, double *n2_out);
+int sd_k_lanczos_fold_scalars(sd_ctx *ctx, int form, const double *dot_dev, const double *n2c_dev, double *store_alpha,
+                              double *store_bc);
 int sd_k_mgs_chain(sd_ctx *ctx, double *w, const double *V, int64_t ld, int ncols, int64_t N, int slot);   // MGS against V[:,0..ncols-2], then dot with V[:,ncols-1] -> d_scalars[slot]
 int sd_k_mdot(sd_ctx *ctx, const double *V, int64_t ld, int ncols, const double *y, int64_t N, double *out_host);   // out[c] = V[:,c].y (real)
 int sd_read_scalars(sd_ctx *ctx, int slot, int count, double *out);
