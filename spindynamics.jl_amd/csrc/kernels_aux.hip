@@ -16,15 +16,19 @@ namespace {
 // =====================================================================
 struct SzqPhases { double re[SD_MAX_L + 1], im[SD_MAX_L + 1]; };
 
-template <int NCIN>
-__device__ __forceinline__ void szq_row(const sd_dev_model &dm, const SzqPhases &ph, double normfact, uint64_t s,
-                                        const double *__restrict__ psi0, int64_t row, double2 *__restrict__ phi) {
-  double sr = 0.0, si = 0.0;
-  for (int r = 0; r < dm.L; ++r) {
+// The site sum runs in site order 1..L (src/Hamiltonian.jl:318-326).  Sites first..last-1 of configuration s are added to
+// (sr, si): a tile passes the sum over its prefix sites -- the FIRST terms of every row's sum, the same for all its rows --
+// and each row adds its LS suffix terms, which are the same additions in the same order as the full loop.
+__device__ __forceinline__ void szq_sum(const SzqPhases &ph, uint64_t s, int first, int last, double &sr, double &si) {
+  for (int r = first; r < last; ++r) {
     const double z = sz_of((s >> r) & 1);
     sr += ph.re[r] * z;
     si += ph.im[r] * z;
   }
+}
+template <int NCIN>
+__device__ __forceinline__ void szq_store(double sr, double si, double normfact, const double *__restrict__ psi0, int64_t row,
+                                          double2 *__restrict__ phi) {
   const double ar = normfact * sr, ai = normfact * si;
   double xr, xi;
   if (NCIN == 2) { xr = psi0[2 * row]; xi = psi0[2 * row + 1]; }
@@ -41,9 +45,12 @@ __global__ __launch_bounds__(256) void k_szq_tiled(sd_dev_model dm, SzqPhases ph
   const int t2 = dm.nup - __popc(P);
   const int len = (int)binom_g(dm, dm.LS, t2);
   const uint16_t *__restrict__ sufS = dm.suf_states + dm.suf_off[t2];
+  double pr = 0.0, pi = 0.0;
+  szq_sum(ph, (uint64_t)P, 0, dm.p, pr, pi);                      // wave-uniform: once per tile
   for (int i = threadIdx.x; i < len; i += blockDim.x) {
-    const uint64_t s = (uint64_t)P | ((uint64_t)sufS[i] << dm.p);
-    szq_row<NCIN>(dm, ph, normfact, s, psi0, base + i, phi);
+    double sr = pr, si = pi;
+    szq_sum(ph, (uint64_t)sufS[i] << dm.p, dm.p, dm.L, sr, si);
+    szq_store<NCIN>(sr, si, normfact, psi0, base + i, phi);
   }
 }
 
@@ -54,7 +61,9 @@ __global__ __launch_bounds__(256) void k_szq_generic(sd_dev_model dm, SzqPhases 
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < dm.n_local; idx += stride) {
     const uint64_t s = full ? (uint64_t)(dm.row_lo + idx) : unrank_g(dm, idx);     // full basis: state = global row
-    szq_row<NCIN>(dm, ph, normfact, s, psi0, idx, phi);
+    double sr = 0.0, si = 0.0;
+    szq_sum(ph, s, 0, dm.L, sr, si);
+    szq_store<NCIN>(sr, si, normfact, psi0, idx, phi);
   }
 }
 
