@@ -25,4 +25,6 @@ res = {"L": L, "dtype": dtype, "source_hash": bench.kernel_source_hash(), "FETCH
        "note": "FETCH_SIZE doubled per the gfx950 half-count of wide coalesced reads; this is traffic on the fabric side of the "
                "L2s (TCC_EA requests): Infinity-Cache hits are included, so it bounds HBM traffic from above"}
 json.dump(res, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "traffic_latest.json"), "w"), indent=1)
+# the GPU box only hands back gpurun_out/: leave a copy there to be committed as profiles/traffic_latest.json
+json.dump(res, open(os.path.join(out, "traffic_latest.json"), "w"), indent=1)
 print(res)
