@@ -11,10 +11,11 @@ def timed(model, dtype, steps=30):
     for _ in range(steps): pkg.apply_H(b, a, model)
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / steps
+LL = int(os.environ.get("SD_ABL_L", "30"))
 for dt in (torch.float64, torch.complex128):
-    for skip in ("", "16", "4", "1", "2", "3", "7"):
+    for skip in ("", "16", "4", "16", "4", "1", "2", "3", "7"):
         if skip: os.environ["SD_DEBUG_SKIP"] = skip
         else: os.environ.pop("SD_DEBUG_SKIP", None)
-        m = pkg.XXZChain(30, nup=15)
+        m = pkg.XXZChain(LL, nup=LL // 2)
         print(json.dumps({"dtype": str(dt), "skip": skip, "ms": timed(m, dt)}), flush=True)
         del m
