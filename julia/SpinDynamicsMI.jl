@@ -16,6 +16,7 @@
 module SpinDynamicsMI
 
 using Random
+using Libdl
 
 export Model, build_model, XXZChain, momenta, apply_H!, apply_rescaled_H!, Sz_q_vector, create_spin_operator,
        groundstate, time_evolve, structure_factor, dynamical_structure_factor,
@@ -156,11 +157,12 @@ end
 function _obs(fname::Symbol, ψ::AbstractVector, model::Model, nout::Int)
     x = eltype(ψ) <: Complex ? Vector{ComplexF64}(ψ) : Vector{Float64}(ψ)
     outs = [Vector{Float64}(undef, model.L) for _ in 1:nout]
+    fptr = Libdl.dlsym(Libdl.dlopen(libspindyn), fname)     # ccall((name, lib), ...) wants a constant name: resolve it here
     if nout == 1
-        check(ccall((fname, libspindyn), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Int64, Ptr{Float64}),
+        check(ccall(fptr, Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Int64, Ptr{Float64}),
                     model.ctx.h, model.h, dtype_code(eltype(x)), x, length(x), outs[1]), model.ctx.h)
     else
-        check(ccall((fname, libspindyn), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{Float64}),
+        check(ccall(fptr, Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{Float64}),
                     model.ctx.h, model.h, dtype_code(eltype(x)), x, length(x), outs[1], outs[2]), model.ctx.h)
     end
     return outs
