@@ -157,7 +157,7 @@ end
 function _obs(fname::Symbol, ψ::AbstractVector, model::Model, nout::Int)
     x = eltype(ψ) <: Complex ? Vector{ComplexF64}(ψ) : Vector{Float64}(ψ)
     outs = [Vector{Float64}(undef, model.L) for _ in 1:nout]
-    fptr = Libdl.dlsym(Libdl.dlopen(libspindyn), fname)     # ccall((name, lib), ...) wants a constant name: resolve it here
+    fptr = Libdl.dlsym(Libdl.dlopen(libspindyn), fname)     # a (name, library) pair must be a literal for ccall: resolve the run-time name here
     if nout == 1
         check(ccall(fptr, Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Int64, Ptr{Float64}),
                     model.ctx.h, model.h, dtype_code(eltype(x)), x, length(x), outs[1]), model.ctx.h)

@@ -275,3 +275,61 @@ def test_class_mode_cuts_halo_volume(pkg, monkeypatch):
             h = max(h, i.n_halo / i.n_local)
         tot[mode] = h
     assert tot["class"] < 0.5 * tot["range"]
+
+
+def _julia_ccalls(text):
+    """(name, return kind, [argument kinds], number of values passed) of every `ccall((:sd_x, libspindyn), Ret, (T...), args...)`"""
+    def jkind(t):
+        t = t.strip()
+        if t.startswith(("Ptr{", "Ref{")) or t == "Cstring":
+            return "ptr"
+        return {"Cint": "int", "Int64": "i64", "UInt64": "u64", "Float64": "double", "Cvoid": "void"}[t]
+
+    def split_top(s):      # split at commas outside (), {} and []
+        parts, depth, cur = [], 0, ""
+        for ch in s:
+            if ch in "({[":
+                depth += 1
+            elif ch in ")}]":
+                depth -= 1
+            if ch == "," and depth == 0:
+                parts.append(cur)
+                cur = ""
+            else:
+                cur += ch
+        if cur.strip():
+            parts.append(cur)
+        return [p.strip() for p in parts]
+
+    calls = []
+    for mt in re.finditer(r"ccall\(\(:(sd_[A-Za-z0-9_]+),\s*libspindyn\)\s*,", text):
+        i, depth = mt.end(), 1            # scan to the parenthesis that closes this ccall
+        while depth:
+            depth += {"(": 1, ")": -1}.get(text[i], 0)
+            i += 1
+        items = split_top(text[mt.end():i - 1])
+        ret, types = items[0], items[1]
+        assert types.startswith("(") and types.endswith(")"), (mt.group(1), types)
+        targs = [jkind(t) for t in split_top(types[1:-1]) if t]
+        calls.append((mt.group(1), jkind(ret), targs, len(items) - 2))
+    return calls
+
+
+@pytest.mark.parametrize("rel", ["julia/SpinDynamicsMI.jl", "INTEGRATION.md"])
+def test_julia_ccalls_match_the_header(rel):
+    """The Julia shim has never been run (no Julia here): at least every ccall in it -- and in INTEGRATION.md's binding
+    examples -- must name an exported function, declare the header's parameter kinds in the header's order, and pass as
+    many values as it declares."""
+    protos = header_prototypes()
+    calls = _julia_ccalls(open(os.path.join(ROOT, rel)).read())
+    assert len(calls) >= (20 if rel.endswith(".jl") else 3)
+    for name, ret, targs, nvals in calls:
+        assert name in protos, f"{rel}: ccall of {name}, which include/spindyn.h does not declare"
+        hret, hargs = protos[name]
+        if name in ("sd_last_error", "sd_status_string"):
+            hret = "ptr"                       # const char * parses as a pointer return
+        assert ret == hret, (rel, name, "return", ret, hret)
+        assert targs == hargs, (rel, name, targs, hargs)
+        assert nvals == len(targs), (rel, name, "values passed", nvals, "declared", len(targs))
+    # a ccall whose name is not a literal cannot be compiled by Julia
+    assert not re.search(r"ccall\(\((?!:)[A-Za-z_]", open(os.path.join(ROOT, rel)).read())
