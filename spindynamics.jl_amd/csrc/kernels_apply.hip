@@ -168,7 +168,14 @@ __global__ __launch_bounds__(BLOCK, 4) void k_apply_tiled(sd_dev_model dm, doubl
 
   // ---- diagonal (needs own) ----
   V acc[R];
-  if (dm.diag_mode == 0 && dm.L <= 64 && dm.n_zz_nn <= 64) {   // list-order diagonal, all rows of the thread at once
+  if (dm.diag_cache) {                                         // general couplings: the diagonal was summed once per model
+    double dd[R];
+    const __amdgpu_buffer_rsrc_t rd = make_rsrc(dm.diag_cache + base, (uint32_t)len * (uint32_t)sizeof(double));
+#pragma unroll
+    for (int r = 0; r < R; ++r) buf_load(dd[r], rd, (uint32_t)(tid + r * BLOCK) * (uint32_t)sizeof(double));
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = vscale(dd[r], own[r]);
+  } else if (dm.diag_mode == 0 && dm.L <= 64 && dm.n_zz_nn <= 64) {   // list-order diagonal, all rows of the thread at once
     double dd[R];
     diag_rows<R>(dm, P, p, sig, lane, dd);
 #pragma unroll

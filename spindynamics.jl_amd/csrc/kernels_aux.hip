@@ -147,6 +147,18 @@ __global__ __launch_bounds__(256) void k_obs_reduce(const double *__restrict__ p
 
 
 
+// ---- the list-order diagonal of every local row, once per model (sd_dev_model::diag_cache) ----
+__global__ __launch_bounds__(256) void k_build_diag(sd_dev_model dm, double *__restrict__ out) {
+  for (int t = blockIdx.x; t < dm.n_tiles; t += gridDim.x) {
+    const uint32_t P = dm.tile_prefix[t];
+    const int64_t base = dm.tile_base[t];
+    const int t2 = dm.nup - __popc(P);
+    const int len = (int)binom_g(dm, dm.LS, t2);
+    const uint16_t *__restrict__ sufS = dm.suf_states + dm.suf_off[t2];
+    for (int i = threadIdx.x; i < len; i += blockDim.x) out[base + i] = diag_of(dm, (uint64_t)P | ((uint64_t)sufS[i] << dm.p));
+  }
+}
+
 // ---- sharded plans: pack the tiles peers need into the contiguous send buffer; fill a local vector by GLOBAL index ----
 template <int NC>
 __global__ __launch_bounds__(256) void k_pack(sd_dev_model dm, const double *__restrict__ psi_, double *__restrict__ send_) {
@@ -204,6 +216,13 @@ __global__ __launch_bounds__(256) void k_spin_op(sd_dev_model dm, int bit_pos, i
   }
 }
 }  // namespace
+
+int sd_k_build_diag(const sd_dev_model &dm, double *out) {
+  if (dm.n_tiles <= 0) return SD_OK;
+  hipLaunchKernelGGL(k_build_diag, dim3((unsigned)std::min(dm.n_tiles, 1 << 16)), dim3(256), 0, 0, dm, out);
+  if (hipGetLastError() != hipSuccess) return SD_EHIP;
+  return hipDeviceSynchronize() == hipSuccess ? SD_OK : SD_EHIP;
+}
 
 // mode 0: out[L] = magnetization per site; mode 1: out[L] = lag sums R_r.  psi is a device vector.
 int sd_launch_observable(sd_ctx *ctx, const sd_model *m, int dtype, const void *psi, int mode, double *out_host) {

@@ -86,6 +86,7 @@ struct sd_dev_model {
   const double *field;
   const double *zz_q;            // (zz_J * 0.5) * 0.5: the exact magnitude of every zz term (diag_mode 0)
   const double *field_h;         // field * 0.5: the exact magnitude of every field term
+  const double *diag_cache;      // list-order diagonal of every local row, computed once (tiled plans without an exact shortcut), or null
   const int64_t *binom;  // (SD_MAX_L+1) x (SD_MAX_L+1) row-major: C(n,k)
   // tiled path tables
   int n_tiles;
@@ -202,6 +203,7 @@ int sd_k_nrm2sq(sd_ctx *ctx, const double *x, int64_t n, int slot);
 // three-term update on un-normalised Lanczos vectors (kernels_blas1.hip, k_lanczos_fold): t <- w, |w|^2 -> n2_out[0..1]
 int sd_k_lanczos_fold(sd_ctx *ctx, double *t, const double *uc, const double *up, int64_t N, int form, const double *dot_dev,
                       const double *n2c_dev, const double *n2p_dev, double *store_alpha, double *store_bc, double *n2_out);
+int sd_k_build_diag(const sd_dev_model &dm, double *out);   // out[local row] = diag_of(row) through the tile tables; synchronous
 int sd_k_lanczos_fold_scalars(sd_ctx *ctx, int form, const double *dot_dev, const double *n2c_dev, double *store_alpha,
                               double *store_bc);
 int sd_k_mgs_chain(sd_ctx *ctx, double *w, const double *V, int64_t ld, int ncols, int64_t N, int slot);   // MGS against V[:,0..ncols-2], then dot with V[:,ncols-1] -> d_scalars[slot]

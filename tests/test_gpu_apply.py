@@ -164,19 +164,24 @@ def test_full_basis_tiled_path(pkg, O):
     assert np.linalg.norm(want - E0 * psi0) < 1e-8          # a converged eigenpair of the oracle's operator
 
 
-@pytest.mark.parametrize("gb", ["2", "3"])
-def test_grouped_kernel_opt_in_bit_exact(pkg, O, gb, monkeypatch):
-    """SD_GROUP_BONDS (experimental, default off): 4/8 tiles related by disjoint flippable top bonds share one
-    workgroup and one LDS image.  Same per-row accumulation order -> still bit-identical to the oracle."""
-    monkeypatch.setenv("SD_GROUP_BONDS", gb)
+@pytest.mark.parametrize("cache", ["0", "1"])
+def test_diagonal_cache_on_off_bit_exact(pkg, O, cache, monkeypatch):
+    """Couplings without an exact shortcut for the diagonal: the list-order sum is evaluated once per model and cached
+    (default) or evaluated inside every apply (SD_DIAG_CACHE=0).  Both are the reference's sequential sum, bit for bit; short
+    tiles (SD_SUFFIX_BITS=8) so that several length classes and many tiles are in play."""
+    monkeypatch.setenv("SD_DIAG_CACHE", cache)
     monkeypatch.setenv("SD_SUFFIX_BITS", "8")
-    for (L, nup) in [(18, 9), (20, 8), (19, 10)]:
-        m = pkg.XXZChain(L, nup=nup, Jz=0.7)
-        r = O.XXZChain(L, nup=nup, Jz=0.7)
-        psi = rand_vec(m.N, 77 + L)
-        out = np.empty_like(psi)
-        pkg.apply_H(out, psi, m)
-        assert np.array_equal(out, O.apply_H(r, psi))
+    for (L, nup, kw) in [(18, 9, dict(Jz=0.7)), (20, 8, dict(Jz=0.7, hz=0.3)), (19, 10, dict(Jxy=0.9, Jz=0.7, hz=0.3)),
+                         (18, 9, dict(Jz=0.7, hz=0.3, boundary="periodic"))]:
+        m = pkg.XXZChain(L, nup=nup, **kw)
+        r = O.XXZChain(L, nup=nup, **kw)
+        for cplx in (True, False):
+            psi = rand_vec(m.N, 77 + L, cplx)
+            out = np.empty_like(psi)
+            pkg.apply_H(out, psi, m)
+            assert np.array_equal(out, O.apply_H(r, psi))
+        psi = rand_vec(m.N, 79 + L)
         a, b = 5.5, 0.25
+        out = np.empty_like(psi)
         pkg.apply_rescaled_H(out, psi, pkg.apply_H, m, a, b)
         assert np.array_equal(out, O.apply_rescaled_H(r, psi, a, b))
