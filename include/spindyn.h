@@ -122,6 +122,17 @@ int sd_apply_rescaled(sd_ctx *ctx, const sd_model *m, int dtype, void *out_host,
                       int64_t n, double a, double b);
 int sd_apply_rescaled_dev(sd_ctx *ctx, const sd_model *m, int dtype, void *out_dev, const void *psi_dev,
                           int64_t n, double a, double b);
+/* The operator as a callable at the recursion level.  Every reference solver takes `applyH!` as an argument
+ * (src/Lanczos.jl:27-29, src/TimeEvolution/Chebyshev.jl:61-64, src/KPM_Sqw.jl:95-98, ...).  With a callback installed,
+ * every recursion entry point of this library (lanczos_*, energy_bounds, krylov / chebyshev evolve, kpm_*, *_sqw, and their
+ * _dev / _sharded forms) calls fn for out <- H psi instead of the built-in kernel and applies its own fused step (rescale,
+ * recurrence, dot products) in a second, elementwise pass.  fn gets DEVICE pointers of n_local elements of `dtype` and the
+ * HIP stream the call must be ordered on (enqueue there, or finish before returning); out never aliases psi; a nonzero
+ * return aborts the call with SD_ECOMM.  The operator-level entries (sd_apply*, sd_apply_sharded*) always run the built-in
+ * operator, so fn may call them on the same model.  On a sharded model fn is responsible for its own halo exchange.
+ * fn == NULL restores the built-in operator. */
+typedef int (*sd_apply_fn)(void *user, int dtype, void *out_dev, const void *psi_dev, int64_t n_local, void *hip_stream);
+int sd_model_set_apply_callback(sd_model *m, sd_apply_fn fn, void *user);
 /* Sz_q_vector   src/Hamiltonian.jl:307-337.  phi_out is always ComplexF64. */
 int sd_szq(sd_ctx *ctx, const sd_model *m, int dtype_in, const void *psi0_host, int64_t n, double q,
            void *phi_out_host);

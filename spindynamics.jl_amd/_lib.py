@@ -46,6 +46,23 @@ class sd_slab(C.Structure):
     _fields_ = [("peer", C.c_int), ("local_offset", C.c_int64), ("count", C.c_int64), ("global_row", C.c_int64)]
 
 
+# sd_apply_fn (include/spindyn.h): the caller's operator at the recursion level (the reference's applyH! argument)
+APPLY_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+
+
+class DevMem:
+    """A raw device pointer as a __cuda_array_interface__ object (Float64 view), so that torch can wrap it without a copy."""
+
+    def __init__(self, ptr, n_doubles):
+        self.__cuda_array_interface__ = {"shape": (int(n_doubles),), "typestr": "<f8", "data": (int(ptr), False),
+                                         "version": 3, "strides": None}
+
+
+def dev_tensor(ptr, n_doubles, device):
+    import torch
+    return torch.as_tensor(DevMem(ptr, n_doubles), device=device)
+
+
 # sd_comm_callbacks (include/spindyn.h): how a sharded recursion exchanges halos and sums scalars
 EXCHANGE_START_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p)
 EXCHANGE_WAIT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
@@ -123,6 +140,7 @@ PROTOTYPES = {
     "sd_apply_sharded_cheb2_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _d, _d, _d, _d, _d, _d, _vp, _vp, _i]),
     "sd_kpm_step_sharded_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _d, _d, _i, _dp]),
     "sd_comm_from_callbacks": (_i, [C.POINTER(sd_comm_callbacks), _i, _i, C.POINTER(_vp)]),
+    "sd_model_set_apply_callback": (_i, [_vp, APPLY_FN, _vp]),
     "sd_comm_rccl_unique_id": (_i, [_vp]),
     "sd_comm_rccl_create": (_i, [_vp, _i, _i, _vp, C.POINTER(_vp)]),
     "sd_comm_destroy": (None, [_vp]),

@@ -290,6 +290,12 @@ void sd_model_destroy(sd_model *m) {
 int64_t sd_model_dim(const sd_model *m) { return m ? m->N : -1; }
 int sd_model_L(const sd_model *m) { return m ? m->L : -1; }
 int sd_model_nup(const sd_model *m) { return m ? m->nup : -2; }
+int sd_model_set_apply_callback(sd_model *m, sd_apply_fn fn, void *user) {
+  if (!m) return SD_EARG;
+  m->user_apply = fn;
+  m->user_apply_data = fn ? user : nullptr;
+  return SD_OK;
+}
 int sd_model_path(const sd_model *m) { return !m ? 0 : m->p >= 0 ? 1 : m->full_ls > 0 ? 2 : 0; }
 
 int sd_model_states(const sd_model *m, int64_t start, int64_t count, uint64_t *out) {

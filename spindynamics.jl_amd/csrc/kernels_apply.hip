@@ -510,6 +510,29 @@ __global__ __launch_bounds__(256) void k_apply_generic(sd_dev_model dm, double *
   }
 }
 
+// epilogue alone, for H psi produced by a caller's operator (sd_model_set_apply_callback): same arithmetic per element as the
+// fused form; out may be hpsi
+template <int NC>
+__global__ __launch_bounds__(256) void k_epilogue_only(int epi, sd_epi_args ea, int64_t n, double *out_,
+                                                       const double *hpsi_, const double *__restrict__ psi_,
+                                                       double *__restrict__ partials) {
+  using V = typename VT<NC>::type;
+  __shared__ double red[32];
+  const V *hpsi = reinterpret_cast<const V *>(hpsi_);
+  const V *__restrict__ psi = reinterpret_cast<const V *>(psi_);
+  EpiSums sums{0.0, 0.0};
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const V acc = hpsi[i], own = psi[i];
+    epilogue<NC>(epi, ea, i, acc, own, out_, sums);
+  }
+  if (epi_has_sums(epi)) {
+    double a = sums.s0, b = sums.s1;
+    block_reduce2(a, b, red);
+    if (threadIdx.x == 0) { partials[2 * (size_t)blockIdx.x] = a; partials[2 * (size_t)blockIdx.x + 1] = b; }
+  }
+}
+
 // fixed-order reduction of the per-block partial pairs -> scalars[0..1]
 __global__ __launch_bounds__(1024) void k_reduce_pairs(const double *__restrict__ partials, int64_t n,
                                                        double *__restrict__ scalars) {
@@ -547,6 +570,27 @@ int sd_reduce_pairs(sd_ctx *ctx, int64_t n, double *dst) {
   }
   hipLaunchKernelGGL(k_reduce_pairs, dim3(1), dim3(1024), 0, ctx->stream, src, n, dst);
   SD_HIP(ctx, hipGetLastError());
+  return SD_OK;
+}
+int sd_launch_epilogue_only(sd_ctx *ctx, int dtype, int64_t n, void *out, const void *hpsi, const void *psi, int epi,
+                            const sd_epi_args &ea_in) {
+  const bool sums = (epi == SD_EPI_DOT || epi == SD_EPI_KPM || epi == SD_EPI_RESCALE_DOT);
+  sd_epi_args ea = ea_in;
+  ea.stream_hint = 0;
+  if (n <= 0) {
+    if (sums) SD_HIP(ctx, hipMemsetAsync(ea.sums_dst ? ea.sums_dst : ctx->d_scalars, 0, 2 * sizeof(double), ctx->stream));
+    return SD_OK;
+  }
+  const int64_t nb = std::min<int64_t>((n + 255) / 256, 4096);
+  if (sums) { int rc = sd_ensure_partials(ctx, 2 * (size_t)nb + 2 * SD_RED_STAGE_BLOCKS); if (rc) return rc; }
+  if (dtype == SD_C128)
+    hipLaunchKernelGGL(k_epilogue_only<2>, dim3((unsigned)nb), dim3(256), 0, ctx->stream, epi, ea, n, (double *)out,
+                       (const double *)hpsi, (const double *)psi, ctx->d_partials);
+  else
+    hipLaunchKernelGGL(k_epilogue_only<1>, dim3((unsigned)nb), dim3(256), 0, ctx->stream, epi, ea, n, (double *)out,
+                       (const double *)hpsi, (const double *)psi, ctx->d_partials);
+  SD_HIP(ctx, hipGetLastError());
+  if (sums) return sd_reduce_pairs(ctx, nb, ea.sums_dst);
   return SD_OK;
 }
 namespace {

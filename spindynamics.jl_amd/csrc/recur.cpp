@@ -60,6 +60,21 @@ int d2d(sd_ctx *ctx, double *dst, const double *src, int64_t doubles) {
   return SD_OK;
 }
 
+// The caller's operator (sd_model_set_apply_callback; the reference's `applyH!` argument): out <- H psi by the callback on the
+// context's stream, then the recursion's fused step as one elementwise pass over out.
+int user_op(sd_ctx *ctx, const sd_model *m, int dtype, double *out, const double *psi, int64_t n, int epi, const sd_epi_args &ea) {
+  if (m->user_apply(m->user_apply_data, dtype, out, psi, n, (void *)ctx->stream))
+    return sd_set_err(ctx, SD_ECOMM, "the apply callback returned an error");
+  if (epi == SD_EPI_PLAIN && !ea.negate) return SD_OK;
+  return sd_launch_epilogue_only(ctx, dtype, n, out, out, psi, epi, ea);
+}
+// out <- H psi for the entry points that run their own loop on an unsharded model
+int plain_op(sd_ctx *ctx, const sd_model *m, int dtype, double *out, const double *psi) {
+  sd_epi_args ea;
+  if (m->user_apply) return user_op(ctx, m, dtype, out, psi, m->n_local, SD_EPI_PLAIN, ea);
+  return sd_launch_apply(ctx, m, dtype, out, psi, SD_EPI_PLAIN, ea);
+}
+
 // What a recursion needs from "the operator": the apply on this rank's rows (halo exchange included) and the sum of device
 // scalars over the ranks.  Unsharded (comm == nullptr, nranks == 1) both reduce to the plain launch / nothing, so the same
 // loops serve the single-GPU and the sharded entry points.
@@ -87,6 +102,7 @@ struct Op {
   }
   // out = epilogue(H psi) on the owned rows.  Sharded: pack (cell mode), post the exchange, interior tiles, wait, boundary tiles.
   int apply(int dtype, double *out, const double *psi, int epi, sd_epi_args ea) {
+    if (m->user_apply) return user_op(ctx, m, dtype, out, psi, n, epi, ea);
     if (m->nranks == 1) return sd_launch_apply(ctx, m, dtype, out, psi, epi, ea, 0);
     ea.halo = halo.p;
     const void *src = psi;
@@ -555,10 +571,9 @@ extern "C" int sd_lanczos_groundstate(sd_ctx *ctx, const sd_model *m, int lanc_m
   RC(sd_k_scale_div(ctx, V.p, V.p, N, nrm));                                             // :100,105
   std::vector<double> alpha(mm, 0.0), beta(mm, 0.0);
   int m_actual = mm;
-  sd_epi_args ea;
   for (int j = 1; j <= mm; ++j) {
     double *vj = V.p + N * (int64_t)(j - 1);
-    RC(sd_launch_apply(ctx, m, SD_F64, w.p, vj, SD_EPI_PLAIN, ea));                       // :113
+    RC(plain_op(ctx, m, SD_F64, w.p, vj));                                                // :113
     double s[2];
     // :116-124: w -= dot(V[:,k], w) V[:,k] for k = 1..j-1, then alpha_j = dot(V[:,j], w) -- one chain of fused
     // subtract-and-dot kernels whose scalars stay on the device; only alpha_j comes back to the host
@@ -882,8 +897,7 @@ extern "C" int sd_lanczos_sqw(sd_ctx *ctx, const sd_model *m, int dtype, const v
   RC(in.alloc(ctx, nc * n)); RC(psic.alloc(ctx, 2 * n)); RC(tmp.alloc(ctx, 2 * n)); RC(phi.alloc(ctx, 2 * n));
   RC(h2d(ctx, in.p, psi0, nc * n));
   RC(sd_k_promote(ctx, psic.p, in.p, nc, n));
-  sd_epi_args ea;
-  RC(sd_launch_apply(ctx, m, SD_C128, tmp.p, psic.p, SD_EPI_PLAIN, ea));                  // src/LanczosSqw.jl:58
+  RC(plain_op(ctx, m, SD_C128, tmp.p, psic.p));                                           // src/LanczosSqw.jl:58
   // E0 = real(dot(conj(psi0c), tmp)) (sic, :59): dot conjugates its first argument again, so this is Re sum psi_i*tmp_i,
   // the product sum WITHOUT conjugation (equal to <psi|H|psi> for a real psi0).  Reduced on the device.
   RC(sd_k_dotu(ctx, psic.p, tmp.p, n, 4));

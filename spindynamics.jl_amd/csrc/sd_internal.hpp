@@ -126,6 +126,8 @@ struct sd_model {
   int64_t fs_halo_off[SD_FS_MAX_RANKS] = {-1, -1, -1, -1, -1, -1, -1, -1};
   int64_t fs_peer_lo[SD_FS_MAX_RANKS] = {0};
   int rank = 0, nranks = 1;
+  sd_apply_fn user_apply = nullptr;   // recursion-level operator supplied by the caller (sd_model_set_apply_callback), or null
+  void *user_apply_data = nullptr;
   int64_t row_lo = 0, row_hi = 0, n_local = 0, n_halo = 0;
   std::vector<uint32_t> tile_prefix;  // local tiles
   std::vector<int64_t> tile_base;
@@ -188,6 +190,9 @@ struct sd_epi_args {
 // partial sums, the reduced values land in ctx->d_scalars[0..1] (device).
 int sd_launch_apply(sd_ctx *ctx, const sd_model *m, int dtype, void *out, const void *psi, int epi,
                     const sd_epi_args &ea, int part = 0);
+// out <- epilogue(hpsi) where hpsi = H psi came from a caller's operator: the fused steps of the recursions as one elementwise pass
+int sd_launch_epilogue_only(sd_ctx *ctx, int dtype, int64_t n, void *out, const void *hpsi, const void *psi, int epi,
+                            const sd_epi_args &ea);
 int sd_launch_observable(sd_ctx *ctx, const sd_model *m, int dtype, const void *psi, int mode, double *out_host);
 int sd_launch_pack(sd_ctx *ctx, const sd_model *m, int dtype, const void *psi, void *sendbuf);
 int sd_launch_fill_randn_local(sd_ctx *ctx, const sd_model *m, int dtype, void *x, uint64_t seed);

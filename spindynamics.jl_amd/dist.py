@@ -30,17 +30,7 @@ class _StagedRequests:
         self.dst_dev.copy_(self.dst_host)
 
 
-class _DevMem:
-    """A raw device pointer as a __cuda_array_interface__ object (Float64 view), so that torch can wrap it without a copy."""
-
-    def __init__(self, ptr, n_doubles):
-        self.__cuda_array_interface__ = {"shape": (int(n_doubles),), "typestr": "<f8", "data": (int(ptr), False),
-                                         "version": 3, "strides": None}
-
-
-def _dev_tensor(ptr, n_doubles, device):
-    import torch
-    return torch.as_tensor(_DevMem(ptr, n_doubles), device=device)
+_dev_tensor = _lib.dev_tensor
 
 
 class TorchComm:

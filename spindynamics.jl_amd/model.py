@@ -59,6 +59,37 @@ class Model:
     def __len__(self):
         return self.N
 
+    def set_apply(self, fn):
+        """Install `fn(out, psi, model)` as the operator of every recursion on this model (the reference's applyH! argument;
+        sd_model_set_apply_callback), or restore the built-in operator with fn=None.  out and psi are torch tensors on the
+        model's device (Float64 or ComplexF64, this rank's rows), valid during the call only; fn runs with torch's current
+        stream set to the library's stream and must write H psi into out."""
+        self._apply_err = None
+        if fn is None:
+            check(lib().sd_model_set_apply_callback(self.h, _lib.APPLY_FN(), None))
+            self._apply_cb = None
+            return
+
+        def tramp(_user, dtype, out_ptr, psi_ptr, n, stream):
+            try:                        # an exception must not unwind through the C frames
+                import torch
+                dev = torch.device("cuda", self.ctx.device)
+                per = 2 if dtype == _lib.SD_C128 else 1
+                out = _lib.dev_tensor(out_ptr, max(int(n), 1) * per, dev)[: int(n) * per]
+                psi = _lib.dev_tensor(psi_ptr, max(int(n), 1) * per, dev)[: int(n) * per]
+                if per == 2:
+                    out, psi = torch.view_as_complex(out.view(-1, 2)), torch.view_as_complex(psi.view(-1, 2))
+                st = torch.cuda.ExternalStream(int(stream), device=dev) if stream else torch.cuda.default_stream(dev)
+                with torch.cuda.stream(st):
+                    fn(out, psi, self)
+                return 0
+            except Exception as e:
+                self._apply_err = e
+                return 1
+
+        self._apply_cb = _lib.APPLY_FN(tramp)       # keeps the trampoline alive
+        check(lib().sd_model_set_apply_callback(self.h, self._apply_cb, None))
+
     # -- basis queries (host) --
     def states_range(self, start, count):
         out = np.empty(count, dtype=np.uint64)

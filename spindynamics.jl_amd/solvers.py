@@ -1,13 +1,17 @@
 """Mirrors of the reference's solver functions; each runs its whole recursion on
 the device through one C-ABI call (include/spindyn.h, "recursion level").
 
-The first positional `applyH` argument of the reference functions is kept for
-signature compatibility and must be hamiltonian.apply_H (the device operator).
+The `applyH` argument of the reference functions is honoured: hamiltonian.apply_H selects the built-in fused
+operator; any other callable `applyH(out, psi, model)` on torch device tensors is installed as the operator of the
+recursion for the duration of the call (sd_model_set_apply_callback: the library calls it for out <- H psi and
+applies its fused step as a second pass).
 Where the reference draws a start vector from Julia's RNG (which cannot be
 reproduced outside Julia) a `psi0=` / `seed=` keyword is offered instead of
 `rng=`.
 """
 import ctypes as C
+import functools
+import inspect
 
 import numpy as np
 
@@ -18,9 +22,30 @@ from .hamiltonian import _bind_torch_stream, _is_torch, apply_H
 _dp = C.POINTER(C.c_double)
 
 
-def _need_apply(applyH):
-    if applyH is not apply_H:
-        raise ArgumentError("the recursions run on the device: pass spindynamics apply_H as applyH")
+def _with_operator(f):
+    """Runs f with its `applyH` argument as the operator of `model`: nothing to do for the built-in apply_H, any other
+    callable is installed as the recursion-level operator for the duration of the call; its own exception, if any, is
+    what the caller sees."""
+    sig = inspect.signature(f)
+
+    @functools.wraps(f)
+    def g(*args, **kw):
+        ba = sig.bind(*args, **kw)
+        applyH, model = ba.arguments["applyH"], ba.arguments["model"]
+        if applyH is apply_H:
+            return f(*args, **kw)
+        if not callable(applyH):
+            raise ArgumentError("applyH must be callable: applyH(out, psi, model)")
+        model.set_apply(applyH)
+        try:
+            return f(*args, **kw)
+        except Exception:
+            if getattr(model, "_apply_err", None) is not None:
+                raise model._apply_err
+            raise
+        finally:
+            model.set_apply(None)
+    return g
 
 
 def _c128(x, n=None, name="vector"):
@@ -41,9 +66,9 @@ def _ptr(x):
     return None if x is None else x.ctypes.data
 
 
+@_with_operator
 def lanczos_extremal(applyH, model, lanc_m=100, tol=1e-12, psi0=None, seed=0, negate=False):
     """lanczos_extremal(applyH!, model; lanc_m, tol, rng) -> (Emin, Emax) -- src/Lanczos.jl:27-84"""
-    _need_apply(applyH)
     p0 = None if psi0 is None else _c128(psi0, model.N, "psi0")
     lo, hi = C.c_double(), C.c_double()
     check(lib().sd_lanczos_extremal(model.ctx.h, model.h, int(lanc_m), float(tol), _ptr(p0), int(seed), int(bool(negate)),
@@ -51,9 +76,9 @@ def lanczos_extremal(applyH, model, lanc_m=100, tol=1e-12, psi0=None, seed=0, ne
     return lo.value, hi.value
 
 
+@_with_operator
 def estimate_energy_bounds(applyH, model, lanc_m=80, psi0_a=None, psi0_b=None, seed=0):
     """estimate_energy_bounds(applyH!, model; lanc_m=80) -> (Emin, Emax) -- src/Lanczos.jl:255-271"""
-    _need_apply(applyH)
     a = None if psi0_a is None else _c128(psi0_a, model.N, "psi0_a")
     b = None if psi0_b is None else _c128(psi0_b, model.N, "psi0_b")
     lo, hi = C.c_double(), C.c_double()
@@ -62,9 +87,9 @@ def estimate_energy_bounds(applyH, model, lanc_m=80, psi0_a=None, psi0_b=None, s
     return lo.value, hi.value
 
 
+@_with_operator
 def lanczos_groundstate(applyH, model, lanc_m=100, tol=1e-12, orthogonalize_tol=1e-10, psi0=None, seed=0):
     """lanczos_groundstate(applyH!, model; lanc_m, tol, orthogonalize_tol, rng) -> (E0, psi_gs) -- src/Lanczos.jl:87-181"""
-    _need_apply(applyH)
     p0 = None
     if psi0 is not None:
         p0 = np.ascontiguousarray(psi0, dtype=np.float64)
@@ -78,9 +103,9 @@ def lanczos_groundstate(applyH, model, lanc_m=100, tol=1e-12, orthogonalize_tol=
     return E0.value, gs
 
 
+@_with_operator
 def lanczos_tridiag(applyH, model, v, lanc_m=100, tol=1e-12):
     """lanczos_tridiag(applyH!, model, v; lanc_m, tol) -> (alpha, beta, norm_v) -- src/Lanczos.jl:196-246"""
-    _need_apply(applyH)
     v = _c128(v)
     n = len(v)
     m = max(min(int(lanc_m), n), 1)
@@ -91,9 +116,9 @@ def lanczos_tridiag(applyH, model, v, lanc_m=100, tol=1e-12):
     return alpha[: me.value].copy(), beta[: max(me.value - 1, 0)].copy(), nv.value
 
 
+@_with_operator
 def krylov_time_evolve(psi0, dt, applyH, model, kry_m=30):
     """krylov_time_evolve(psi0, dt, applyH!, model; kry_m) -> psi(t) ComplexF64, normalised -- src/TimeEvolution/Krylov.jl:136-192"""
-    _need_apply(applyH)
     if _is_torch(psi0):          # device-resident state
         import torch
         if psi0.dtype not in (torch.float64, torch.complex128):
@@ -110,10 +135,10 @@ def krylov_time_evolve(psi0, dt, applyH, model, kry_m=30):
     return out
 
 
+@_with_operator
 def chebyshev_time_evolve(psi0, dt, applyH, model, cheb_n=100, Ebounds=(-1.0, 1.0), workspace=None):
     """chebyshev_time_evolve(psi0, dt, applyH!, model; cheb_n, Ebounds) -- src/TimeEvolution/Chebyshev.jl:61-124.
     psi0 must be complex (the reference's workspace is typed by psi0 and receives complex coefficients)."""
-    _need_apply(applyH)
     if _is_torch(psi0):          # device-resident state: no PCIe per step of a time evolution
         import torch
         if psi0.dtype != torch.complex128:
@@ -161,9 +186,9 @@ def get_kernel(M, kernel="jackson"):
     return g
 
 
+@_with_operator
 def compute_chebyshev_moments(applyH, phi, M, a, b, model):
     """compute_chebyshev_moments(apply_H!, phi, M, a, b, model) -- src/KPM_Sqw.jl:95-128"""
-    _need_apply(applyH)
     phi = _c128(phi)
     mu = np.empty(int(M))
     check(lib().sd_kpm_moments(model.ctx.h, model.h, phi.ctypes.data, len(phi), int(M), float(a), float(b),

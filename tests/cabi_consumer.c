@@ -31,6 +31,15 @@ static double maxdiff(const double *a, const double *b, int64_t n) {
   return d;
 }
 
+/* the reference's applyH! argument as a C callback (sd_apply_fn): forwards to the built-in operator and counts its calls */
+struct fwd { sd_ctx *ctx; const sd_model *model; int calls; };
+static int forward_apply(void *user, int dtype, void *out_dev, const void *psi_dev, int64_t n, void *hip_stream) {
+  struct fwd *f = (struct fwd *)user;
+  (void)hip_stream;                       /* sd_apply_dev runs on the context's stream, which is the one handed in */
+  f->calls++;
+  return sd_apply_dev(f->ctx, f->model, dtype, out_dev, psi_dev, n);
+}
+
 int main(int argc, char **argv) {
   sd_ctx *ctx = NULL;
   sd_model *model = NULL;
@@ -79,6 +88,20 @@ int main(int argc, char **argv) {
   for (i = 0; i < 2 * N; ++i) phi[i] /= nrm;
   CHECK(sd_kpm_moments(ctx, model, phi, N, (int)M, par[6], par[7], mu_got));          /* src/KPM_Sqw.jl:95-128 */
   if (maxdiff(mu_got, mu, M) > 1e-11) { fprintf(stderr, "sd_kpm_moments: %g\n", maxdiff(mu_got, mu, M)); return 1; }
+
+  {   /* the same moments through a caller-supplied operator */
+    struct fwd f;
+    double *mu_cb = (double *)malloc(sizeof(double) * (size_t)M);
+    f.ctx = ctx; f.model = model; f.calls = 0;
+    CHECK(sd_model_set_apply_callback(model, forward_apply, &f));
+    CHECK(sd_kpm_moments(ctx, model, phi, N, (int)M, par[6], par[7], mu_cb));
+    CHECK(sd_model_set_apply_callback(model, NULL, NULL));
+    if (f.calls < 1 || maxdiff(mu_cb, mu_got, M) > 1e-13) {
+      fprintf(stderr, "apply callback: %d calls, moments differ by %g\n", f.calls, maxdiff(mu_cb, mu_got, M));
+      return 1;
+    }
+    free(mu_cb);
+  }
 
   CHECK(sd_ctx_synchronize(ctx));
   sd_model_destroy(model);

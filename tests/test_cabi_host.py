@@ -39,6 +39,8 @@ def header_prototypes():
             return "ptr"
         t = re.sub(r"\b(const|unsigned)\b", "", t).split()
         base = t[0] if t else "void"
+        if base == "sd_apply_fn":          # a function-pointer typedef
+            return "ptr"
         return {"int": "int", "int64_t": "i64", "uint64_t": "u64", "double": "double", "void": "void"}[base]
 
     out = {}

@@ -44,7 +44,7 @@ def test_boundary_errors(pkg):
     with pytest.raises(pkg.ArgumentError):
         pkg.compute_chebyshev_moments(pkg.apply_H, np.ones(m.N, complex), 1, 1.0, 0.0, m)   # kpm_m >= 2
     with pytest.raises(pkg.ArgumentError):
-        pkg.lanczos_extremal(lambda *a: None, m)               # the device recursions need the device operator
+        pkg.lanczos_extremal(None, m)                          # applyH must be apply_H or a callable (applyH(out, psi, model))
 
 
 def test_torch_device_tensors_and_streams(pkg, O):

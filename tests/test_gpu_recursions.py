@@ -361,3 +361,59 @@ def test_long_queued_lanczos_stops_soon_after_a_breakdown(pkg):
     assert dt < 0.05                                  # 5000 queued steps would take ~0.1 s even at 20 us each
     lo, hi = pkg.lanczos_extremal(pkg.apply_H, m, lanc_m=300, psi0=v)
     assert abs(lo - (L - 1) / 4) < 1e-13 and abs(hi - (L - 1) / 4) < 1e-13
+
+
+def test_user_operator_at_recursion_level(pkg, O):
+    """The reference's solvers take the operator as a callable (src/Lanczos.jl:27-29, src/TimeEvolution/Chebyshev.jl:61-64,
+    src/KPM_Sqw.jl:95-98).  A user callable applyH(out, psi, model) on device tensors replaces the built-in kernel inside every
+    recursion (sd_model_set_apply_callback): here 2*H written as a closure over the library's own apply, against the built-in
+    operator of the model with doubled couplings (a power-of-two scale: every intermediate doubles exactly)."""
+    L, nup = 12, 6
+    m = pkg.XXZChain(L, nup=nup, Jz=0.7, hz=0.1)
+    m2 = pkg.XXZChain(L, nup=nup, Jxy=2.0, Jz=1.4, hz=0.2)
+    calls = []
+
+    def twice(out, psi, model):
+        assert out.is_cuda and psi.is_cuda and out.shape == psi.shape == (model.N,)
+        calls.append(psi.dtype)
+        pkg.apply_H(out, psi, model)
+        out.mul_(2.0)
+
+    psi0 = cvec(m.N, 5)
+    psi0 /= np.linalg.norm(psi0)
+    lo, hi = pkg.lanczos_extremal(twice, m, lanc_m=60, psi0=psi0)
+    lo2, hi2 = pkg.lanczos_extremal(pkg.apply_H, m2, lanc_m=60, psi0=psi0)
+    assert abs(lo - lo2) < 1e-10 and abs(hi - hi2) < 1e-10 and len(calls) >= 60
+    al, be, nv = pkg.lanczos_tridiag(twice, m, psi0, lanc_m=20)
+    al2, be2, nv2 = pkg.lanczos_tridiag(pkg.apply_H, m2, psi0, lanc_m=20)
+    assert np.allclose(al, al2, atol=1e-11) and np.allclose(be, be2, atol=1e-11)
+    a = pkg.chebyshev_time_evolve(psi0, 0.3, twice, m, cheb_n=40, Ebounds=(2 * lo2 / 2 - 1.0, hi2 + 1.0))
+    b = pkg.chebyshev_time_evolve(psi0, 0.3, pkg.apply_H, m2, cheb_n=40, Ebounds=(2 * lo2 / 2 - 1.0, hi2 + 1.0))
+    assert np.abs(a - b).max() < 1e-13
+    a = pkg.krylov_time_evolve(psi0, 0.3, twice, m, kry_m=20)
+    b = pkg.krylov_time_evolve(psi0, 0.3, pkg.apply_H, m2, kry_m=20)
+    assert np.abs(a - b).max() < 1e-12
+    aa, bb = pkg.rescaling_from_bounds(lo2, hi2)
+    mu = pkg.compute_chebyshev_moments(twice, psi0, 33, aa, bb, m)
+    mu2 = pkg.compute_chebyshev_moments(pkg.apply_H, psi0, 33, aa, bb, m2)
+    assert np.abs(mu - mu2).max() < 1e-13
+    x0 = np.random.default_rng(3).standard_normal(m.N)
+    calls.clear()
+    E, gs = pkg.lanczos_groundstate(twice, m, lanc_m=50, psi0=x0)
+    E2, gs2 = pkg.lanczos_groundstate(pkg.apply_H, m2, lanc_m=50, psi0=x0)
+    assert abs(E - E2) < 1e-10 and calls and all(str(d) == "torch.float64" for d in calls)
+    # against the oracle's operator too: E is the ground energy of 2 H
+    r2 = O.XXZChain(L, nup=nup, Jxy=2.0, Jz=1.4, hz=0.2)
+    assert np.linalg.norm(O.apply_H(r2, gs) - E * gs) < 1e-6
+
+    # the caller's exception is what comes back, and the built-in operator is in place again afterwards
+    def bad(out, psi, model):
+        raise ValueError("boom")
+
+    with pytest.raises(ValueError, match="boom"):
+        pkg.lanczos_extremal(bad, m, lanc_m=10, psi0=psi0)
+    n_before = len(calls)
+    lo3, hi3 = pkg.lanczos_extremal(pkg.apply_H, m, lanc_m=60, psi0=psi0)
+    assert len(calls) == n_before and abs(2 * lo3 - lo) < 1e-10
+    with pytest.raises(pkg.ArgumentError):
+        pkg.lanczos_extremal("not callable", m)
