@@ -40,9 +40,12 @@ def n_up_first(P):
 tiles = [P for P in range(1 << p) if LO <= tile_len(P) <= HI]
 
 
+PMAX = p - int(os.environ.get("EXCL", "0"))          # EXCL=2: the last odd bond (p-1, p) is never a generator
+
+
 def canon(P):
     C0, member, ng, b = P, 0, 0, 1
-    while b + 1 <= p and ng < FO:
+    while b + 1 <= PMAX and ng < FO:
         if ((P >> (b - 1)) ^ (P >> b)) & 1:
             if not (P >> (b - 1)) & 1:
                 C0 ^= 3 << (b - 1)
@@ -82,6 +85,24 @@ def deal(orbs, name):
         k = int(name[5:])
         for o, (_, ps) in enumerate(orbs):
             q[(o % (8 * k)) // k].extend(ps)
+    elif name.startswith("pair"):
+        # orbits that differ in the last prefix site only (straddle partners) back to back on one XCD, k such pairs per turn
+        k = int(name[4:] or 1)
+        key = {}
+        srt = sorted(range(len(orbs)), key=lambda i: (orbs[i][0] & ~(1 << (p - 1)), (orbs[i][0] >> (p - 1)) & 1))
+        first = {}
+        order = []
+        for i in srt:
+            order.append(i)
+        # keep the first-seen order of the pairs
+        grp = {}
+        for i in range(len(orbs)):
+            grp.setdefault(orbs[i][0] & ~(1 << (p - 1)), []).append(i)
+        o = 0
+        for g, members in grp.items():
+            for i in members:
+                q[(o // k) % 8].extend(orbs[i][1])
+            o += 1
     elif name.startswith("hi"):
         k = int(name[2:].split("x")[0])
         oc = int(name.split("x")[1]) if "x" in name else 1
