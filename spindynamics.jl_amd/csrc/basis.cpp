@@ -774,13 +774,13 @@ int sd_upload_model(sd_model *m, std::string &err) {
     if ((rc = up(m, m->single_base, &d.single_base, err))) return rc;
   }
   // General couplings (no exact shortcut for the diagonal): the reference's sequential sum of up to 2L-1 rounded terms per
-  // row is evaluated once per model and read back as 8 B/row by every apply -- the same bits for a third of the time the
-  // per-apply evaluation costs (profiles/couplings_bench.py).  Default: when there are field terms or zz bonds beyond the chain.
-  // SD_DIAG_CACHE=0 keeps the evaluation in the kernel, =1 caches for every list-order diagonal; a failed allocation (the
-  // cache is half a ComplexF64 vector) falls back to the evaluation.
-  const bool costly_diag = !d.field_zero || d.n_zz > d.n_zz_nn;     // chain zz terms alone cost the same either way (measured)
+  // row is evaluated once per model and read back as 8 B/row by every apply -- the same bits, as fast as the hand-tuned
+  // in-kernel sum for the chain terms alone and 10 % faster with field terms (profiles/couplings_bench.py) -- and, above all,
+  // the in-kernel evaluation for all rows of a thread at once cost the apply kernel 19 VGPRs, i.e. one wave per SIMD, on
+  // EVERY path (KPM step at L=30: 3.03 -> 3.39 ms).  SD_DIAG_CACHE=0 evaluates inside the kernel (prefix part per thread,
+  // the rest per row); a failed allocation (the cache is half a ComplexF64 vector) does the same.
   const char *dc_env = getenv("SD_DIAG_CACHE");
-  if (m->p >= 0 && d.diag_mode == 0 && d.n_local > 0 && d.n_tiles > 0 && (dc_env ? atoi(dc_env) != 0 : costly_diag)) {
+  if (m->p >= 0 && d.diag_mode == 0 && d.n_local > 0 && d.n_tiles > 0 && !(dc_env && atoi(dc_env) == 0)) {
     void *dc = nullptr;
     if (hipMalloc(&dc, sizeof(double) * (size_t)d.n_local) == hipSuccess) {
       m->dev_allocs.push_back(dc);

@@ -299,77 +299,6 @@ __device__ __forceinline__ int64_t rl64(int64_t v, int lane) {
 }
 __device__ __forceinline__ double rld(double v, int lane) { return __longlong_as_double(rl64(__double_as_longlong(v), lane)); }
 
-// List-order diagonal (diag_mode 0) of the R rows of a tile at once: bit for bit the sum of diag_of / diag_head + diag_tail
-// (fields of sites 1..L, then the chain zz bonds, then any further zz bonds, each term +-(h_i/2) or +-(J_k/4) exactly), but
-//  * the coefficients come from two lane tables (lane l holds field_h[l] and zz_q[l]) through v_readlane -- no scalar load,
-//    hence no memory latency, inside the term loops;
-//  * one loop over the terms serves all R rows;
-//  * a term whose sites both lie in the prefix has the same sign for every row of the tile (with fields present the 31 chain
-//    zz terms follow the row-dependent field terms, so they cannot be pre-summed, but 19 of them are one add per row);
-//  * the sign is applied by flipping the sign bit of the coefficient's high word (one xor instead of two selects).
-// sig[r] = suffix configuration of row r; d[r] receives the diagonal element.
-template <int R>
-__device__ __forceinline__ void diag_rows(const sd_dev_model &dm, uint32_t P, int p, const uint32_t (&sig)[R], int lane,
-                                          double (&d)[R]) {
-  const double tf = (!dm.field_zero && lane < dm.L) ? dm.field_h[lane] : 0.0;
-  const double tq = lane < dm.n_zz_nn ? dm.zz_q[lane] : 0.0;
-  auto signed_add = [](double acc, double c, uint32_t minus) {     // acc + (minus ? -c : c), minus in {0, 1}
-    const uint64_t b = (uint64_t)__double_as_longlong(c) ^ ((uint64_t)minus << 63);
-    return acc + __longlong_as_double((long long)b);
-  };
-  double head = 0.0;
-  int k0 = 0;                                     // first chain zz term still to be added per row
-  if (!dm.field_zero) {
-    for (int i = 0; i < p; ++i) head = signed_add(head, rld(tf, i), ((P >> i) & 1u) ^ 1u);           // +h/2 for an up spin
-  } else if (dm.n_zz_nn > 0 && p >= 2) {
-    const uint32_t xp = P ^ (P >> 1);
-    for (int k = 0; k < p - 1; ++k) head = signed_add(head, rld(tq, k), (xp >> k) & 1u);           // -J/4 for an anti-parallel pair
-    k0 = p - 1;
-  }
-#pragma unroll
-  for (int r = 0; r < R; ++r) d[r] = head;
-  if (!dm.field_zero)
-    for (int i = p; i < dm.L; ++i) {
-      const double f = rld(tf, i);
-#pragma unroll
-      for (int r = 0; r < R; ++r) d[r] = signed_add(d[r], f, ((sig[r] >> (i - p)) & 1u) ^ 1u);
-    }
-  const int nzz = dm.n_zz_nn;
-  const uint32_t xp = P ^ (P >> 1);               // bit k: prefix sites k+1, k+2 anti-parallel (k <= p-2)
-  for (int k = k0; k < nzz && k < p - 1; ++k) {   // both sites in the prefix: one sign for the whole tile
-    const double q = rld(tq, k);
-    const double t = ((xp >> k) & 1u) ? -q : q;
-#pragma unroll
-    for (int r = 0; r < R; ++r) d[r] = d[r] + t;
-  }
-  if (p == 0) {                                   // the tile is the whole sector: every chain bond lies in the suffix
-    for (int k = k0; k < nzz; ++k) {
-      const double q = rld(tq, k);
-#pragma unroll
-      for (int r = 0; r < R; ++r) d[r] = signed_add(d[r], q, ((sig[r] ^ (sig[r] >> 1)) >> k) & 1u);
-    }
-  } else if (nzz > p - 1) {
-    const int kb = k0 > p - 1 ? k0 : p - 1;
-    uint32_t xs[R];                               // bit 0: site p vs first suffix site; bit j >= 1: suffix sites j, j+1
-#pragma unroll
-    for (int r = 0; r < R; ++r) xs[r] = (((sig[r] ^ (sig[r] >> 1)) << 1) | ((sig[r] ^ (P >> (p - 1))) & 1u));
-    for (int k = kb; k < nzz; ++k) {
-      const double q = rld(tq, k);
-#pragma unroll
-      for (int r = 0; r < R; ++r) d[r] = signed_add(d[r], q, (xs[r] >> (k - (p - 1))) & 1u);
-    }
-  }
-  for (int k = dm.n_zz_nn; k < dm.n_zz; ++k) {    // zz bonds beyond the chain (periodic closure, long range): as diag_of
-    const double q = dm.zz_q[k];
-    const int bi = dm.zz_i[k] - 1, bj = dm.zz_j[k] - 1;
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const uint64_t s = (uint64_t)P | ((uint64_t)sig[r] << p);
-      d[r] = signed_add(d[r], q, (uint32_t)(((s >> bi) ^ (s >> bj)) & 1));
-    }
-  }
-}
-
 struct FarBond { int64_t base; double J; int lo, n; };   // partner rows: psi[base + (i - lo)] for lo <= i < lo + n
 
 // 128-bit buffer descriptor over [p, p + bytes): loads with a byte offset >= bytes return 0 (hardware range check),

@@ -175,11 +175,13 @@ __global__ __launch_bounds__(BLOCK, 4) void k_apply_tiled(sd_dev_model dm, doubl
     for (int r = 0; r < R; ++r) buf_load(dd[r], rd, (uint32_t)(tid + r * BLOCK) * (uint32_t)sizeof(double));
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[r] = vscale(dd[r], own[r]);
-  } else if (dm.diag_mode == 0 && dm.L <= 64 && dm.n_zz_nn <= 64) {   // list-order diagonal, all rows of the thread at once
-    double dd[R];
-    diag_rows<R>(dm, P, p, sig, lane, dd);
+  } else if (dm.diag_mode == 0) {     // no cache (SD_DIAG_CACHE=0 or no memory): the prefix part of the list-order sum once per thread, the rest per row
+    const DiagHead dh = diag_head(dm, P, p);
 #pragma unroll
-    for (int r = 0; r < R; ++r) acc[r] = vscale(dd[r], own[r]);
+    for (int r = 0; r < R; ++r) {
+      const uint64_t s = (uint64_t)P | ((uint64_t)sig[r] << p);
+      acc[r] = vscale(diag_tail(dm, dh, s, p), own[r]);
+    }
   } else {
 #pragma unroll
     for (int r = 0; r < R; ++r) {
