@@ -146,7 +146,7 @@ static int count_nn_hops(const sd_model *m) {
 static void xcd_order(const sd_model *m, int p, std::vector<uint32_t> &tp_io, std::vector<int64_t> &tb_io,
                       std::vector<int64_t> &first_seen) {
   {
-    int FO = 6;
+    int FO = 5;     // measured with 5 workgroups per CU in flight (profiles/ablation_r02.md §14): 5 beats 6 by 1 % at L=28..32
     if (const char *e = getenv("SD_XCD_ORBIT")) FO = atoi(e);
     if (FO > 8) FO = 8;
     int CH = 32;
