@@ -25,6 +25,13 @@ for name, dt in (("c128", torch.complex128), ("f64", torch.float64)):
     e1.record(); torch.cuda.synchronize()
     res[name] = round(e0.elapsed_time(e1) / 30, 4)
     del a, b
+op = pkg.ShardedOperator(m, 0, 1)
+phi = op.empty(torch.complex128, "cuda"); op.fill_randn(phi, 3); phi /= op.norm(phi)
+op.kpm_moments(phi, 8, 20.0, 0.0)
+import time
+torch.cuda.synchronize(); t0 = time.time()
+op.kpm_moments(phi, 128, 20.0, 0.0)
+torch.cuda.synchronize(); res["kpm_step"] = round((time.time() - t0) / 64 * 1e3, 4)
 print(json.dumps(res))
 '''
 for _ in range(reps):

@@ -311,6 +311,9 @@ __device__ __forceinline__ void buf_load(double &v, __amdgpu_buffer_rsrc_t r, ui
   const u2 raw = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0);
   v = __hiloint2double((int)raw.y, (int)raw.x);
 }
+__device__ __forceinline__ uint32_t buf_load_u16(__amdgpu_buffer_rsrc_t r, uint32_t off) {
+  return (uint32_t)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, off, 0, 0);
+}
 __device__ __forceinline__ void buf_load(double2 &v, __amdgpu_buffer_rsrc_t r, uint32_t off) {
   typedef unsigned int u4 __attribute__((ext_vector_type(4)));
   const u4 raw = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);

@@ -98,17 +98,15 @@ __global__ __launch_bounds__(BLOCK, 4) void k_apply_tiled(sd_dev_model dm, doubl
   // ---- 1. request own rows (rows >= len read 0 through the range check) and suffix configurations ----
   V own[R];
   uint32_t sig[R];
-  uint32_t ioff[R];   // byte offset of the row inside a tile-sized stream
-  int irow[R];        // row index clamped into the tile (LDS addressing of idle rows)
+  const uint32_t off0 = (uint32_t)tid * ES;   // byte offset of the thread's first row inside a tile-sized stream; row r: + r*BLOCK*ES
   {
     const __amdgpu_buffer_rsrc_t rs = make_rsrc(psi + base, (uint32_t)len * ES);
+    const __amdgpu_buffer_rsrc_t rsig = make_rsrc(sufS, (uint32_t)len * 2u);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int i = tid + r * BLOCK;
-      ioff[r] = (uint32_t)i * ES;
-      irow[r] = i < len ? i : len - 1;
-      buf_load(own[r], rs, ioff[r]);
-      sig[r] = sufS[irow[r]];
+      buf_load(own[r], rs, off0 + (uint32_t)(r * BLOCK) * ES);
+      sig[r] = buf_load_u16(rsig, (uint32_t)i * 2u);      // rows >= len: 0 -> no suffix bond flips, the idle row only ever reads the zero row
     }
   }
 
@@ -152,9 +150,9 @@ __global__ __launch_bounds__(BLOCK, 4) void k_apply_tiled(sd_dev_model dm, doubl
     // partner tile lives in the owned rows, or (sharded plans) in the halo imported from its owner
     const V *__restrict__ pb = (halo && fb.base >= dm.n_local) ? halo + (fb.base - dm.n_local) : psi + fb.base;
     const __amdgpu_buffer_rsrc_t rs = make_rsrc(pb, (uint32_t)fb.n * ES);
-    const uint32_t lo_b = (uint32_t)fb.lo * ES;
+    const uint32_t rel = off0 - (uint32_t)fb.lo * ES;      // wraps for rows below the window: the range check returns 0
 #pragma unroll
-    for (int r = 0; r < R; ++r) buf_load(v[r], rs, ioff[r] - lo_b);
+    for (int r = 0; r < R; ++r) buf_load(v[r], rs, rel + (uint32_t)(r * BLOCK) * ES);
   };
 
   SD_STAMP(1);
@@ -191,7 +189,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_apply_tiled(sd_dev_model dm, doubl
   }
 #pragma unroll
   for (int r = 0; r < R; ++r)
-    if (tid + r * BLOCK < len) tile[irow[r]] = own[r];
+    if (tid + r * BLOCK < len) tile[tid + r * BLOCK] = own[r];
   if (tid == 0) tile[max_len] = V{};   // the zero row read by lanes whose suffix bond is not flippable
   for (int k = tid; k < 16 * SD_BIN_STRIDE; k += BLOCK) {
     int n = k / SD_BIN_STRIDE, kk = k - n * SD_BIN_STRIDE;
@@ -251,7 +249,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_apply_tiled(sd_dev_model dm, doubl
   };
   auto gvalue = [&](const GBond &g, int r) -> V {         // psi at the partner row of row r (call only when gflip)
     if (g.kind == 1) return tile[dm.suf_rank[sig[r] ^ g.smask]];
-    const int64_t idx = g.base + (g.kind == 0 ? (int64_t)irow[r] : (int64_t)dm.suf_rank[sig[r] ^ g.smask]);
+    const int64_t idx = g.base + (g.kind == 0 ? (int64_t)(tid + r * BLOCK) : (int64_t)dm.suf_rank[sig[r] ^ g.smask]);
     return (halo && idx >= dm.n_local) ? halo[idx - dm.n_local] : psi[idx];
   };
   // the first general bond's values are requested now, into the idle stream registers, so that their latency hides behind
@@ -281,7 +279,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_apply_tiled(sd_dev_model dm, doubl
       for (int r = 0; r < R; ++r) {
         const bool up = (sig[r] >> (a - 1)) & 1u;
         const bool fl = (dw[r] >> (a - 1)) & 1u;
-        const int ip = up ? irow[r] + d[r] : irow[r] - d[r];
+        const int ip = (tid + r * BLOCK) + (up ? d[r] : -d[r]);
         v[r] = tile[fl ? ip : max_len];
       }
 #pragma unroll
