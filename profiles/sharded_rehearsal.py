@@ -63,6 +63,10 @@ for mode in ("class", "range"):
     S_ref = pkg.kpm_sqw(psi, full, q, omega, a=a, b=b, kpm_m=40)
     ok &= bool(np.abs(S - S_ref).max() <= 1e-10 * max(1.0, np.abs(S_ref).max()))
     sys.stdout.write("rank %d of %d mode %s n_local %d n_halo %d sharded == single: %s\n" % (rank, world, mode, op.n_local, op.n_halo, bool(ok)))
+    routes = op.relay_plan()
+    if routes is not None:          # SD_RELAY=1: which part of the exchange took two hops
+        sys.stdout.write("rank %d mode %s relayed elements per exchange: %d of %d\n" % (
+            rank, mode, sum(hi - lo for lst in routes.values() for (k, lo, hi) in lst if k >= 0), sum(hi for lst in routes.values() for (k, lo, hi) in lst[-1:])))
     sys.stdout.flush()
 dist.barrier()
 dist.destroy_process_group()

@@ -33,6 +33,101 @@ class _StagedRequests:
 _dev_tensor = _lib.dev_tensor
 
 
+def relay_routes(M, chunks=8, min_elems=0, force=False):
+    """Two-hop routing of halo messages through peers whose links would idle (opt-in, SD_RELAY=1).
+    M[(owner, receiver)] = elements of the pair's message.  Every message of at least min_elems elements is cut into `chunks`
+    pieces; each piece takes the path -- direct, or owner -> k -> receiver -- that keeps (busiest link of round 1) + (busiest
+    link of round 2) smallest, largest pieces first (the greedy of profiles/relay_sim.py; ties by rank index, so every rank
+    computes the same plan).  Rounds are sequential, so the plan is kept only if the two busiest links together carry less than
+    the busiest direct message; otherwise everything stays direct (force=True, SD_RELAY=2, keeps it regardless: tests).  Returns {(owner, receiver): [(via or -1, lo, hi), ...]}:
+    element ranges of the message, pieces of one path merged."""
+    ranks = sorted({a for pr in M for a in pr})
+    l1, l2 = {}, {}
+    pieces = []
+    for (o, r), n in M.items():
+        c = chunks if n >= max(min_elems, chunks) else 1
+        for k in range(c):
+            pieces.append((n * (k + 1) // c - n * k // c, o, r))
+    pieces.sort(key=lambda t: (-t[0], t[1], t[2]))
+    count = {}
+    for sz, o, r in pieces:
+        if sz == 0:
+            continue
+        m1, m2 = max(l1.values(), default=0), max(l2.values(), default=0)
+        best = (max(m1, l1.get((o, r), 0) + sz) + m2, l1.get((o, r), 0) + sz, -1)
+        if M[(o, r)] >= max(min_elems, chunks):
+            for k in ranks:
+                if k == o or k == r:
+                    continue
+                a, b = l1.get((o, k), 0) + sz, l2.get((k, r), 0) + sz
+                cand = (max(m1, a) + max(m2, b), max(a, b), k)
+                if cand[:2] < best[:2]:
+                    best = cand
+        k = best[2]
+        if k < 0:
+            l1[(o, r)] = l1.get((o, r), 0) + sz
+        else:
+            l1[(o, k)] = l1.get((o, k), 0) + sz
+            l2[(k, r)] = l2.get((k, r), 0) + sz
+        count.setdefault((o, r), {})
+        count[(o, r)][k] = count[(o, r)].get(k, 0) + sz
+    if not force and max(l1.values(), default=0) + max(l2.values(), default=0) >= max(M.values(), default=0):
+        return {pr: [(-1, 0, n)] for pr, n in M.items() if n > 0}     # the two rounds together are no shorter than the busiest direct message
+    routes = {}
+    for pr, per_via in count.items():
+        lo, lst = 0, []
+        for k in sorted(per_via):
+            lst.append((k, lo, lo + per_via[k]))
+            lo += per_via[k]
+        assert lo == M[pr]
+        routes[pr] = lst
+    return routes
+
+
+class _RelayExchange:
+    """One halo exchange over the routes of relay_routes: round 1 = direct pieces and first hops, round 2 = second hops out
+    of the relays' buffers.  Both sides of every pair post their operations in the same canonical order (sorted pairs, pieces
+    in route order), which is what matches messages between two ranks.  wait() completes round 1, posts and completes round 2."""
+
+    def __init__(self, op, routes, src, dst, per, group, finish=None):
+        import torch
+        import torch.distributed as dist
+        me, nl = op.rank, op.n_local
+        send_at = {peer: off for (peer, off, cnt, _g) in op.send_slabs}
+        recv_at = {peer: off - nl for (peer, off, cnt, _g) in op.recv_slabs}
+        n_relay = sum(hi - lo for pr in routes for (k, lo, hi) in routes[pr] if k == me)
+        relay = torch.empty(max(n_relay, 1) * per, dtype=src.dtype, device=src.device)
+        r1, self._r2, slot = [], [], 0
+        for (o, r) in sorted(routes):
+            for (k, lo, hi) in routes[(o, r)]:
+                n = hi - lo
+                if k < 0:
+                    if me == o:
+                        r1.append(dist.P2POp(dist.isend, src[(send_at[r] + lo) * per:(send_at[r] + hi) * per], r, group))
+                    if me == r:
+                        r1.append(dist.P2POp(dist.irecv, dst[(recv_at[o] + lo) * per:(recv_at[o] + hi) * per], o, group))
+                    continue
+                if me == o:
+                    r1.append(dist.P2POp(dist.isend, src[(send_at[r] + lo) * per:(send_at[r] + hi) * per], k, group))
+                if me == k:
+                    buf = relay[slot * per:(slot + n) * per]
+                    slot += n
+                    r1.append(dist.P2POp(dist.irecv, buf, o, group))
+                    self._r2.append(dist.P2POp(dist.isend, buf, r, group))
+                if me == r:
+                    self._r2.append(dist.P2POp(dist.irecv, dst[(recv_at[o] + lo) * per:(recv_at[o] + hi) * per], k, group))
+        self._relay, self._finish, self._dist = relay, finish, dist
+        self._reqs = dist.batch_isend_irecv(r1) if r1 else []
+
+    def wait(self):
+        for r in self._reqs:
+            r.wait()
+        for r in (self._dist.batch_isend_irecv(self._r2) if self._r2 else []):
+            r.wait()
+        if self._finish is not None:
+            self._finish()
+
+
 class TorchComm:
     """sd_comm (include/spindyn.h) whose callbacks move the bytes with torch.distributed: what the C recursion-level entry
     points (sd_*_sharded) call for the halo exchange of each apply and for the sum of the scalars of each reduction.
@@ -64,6 +159,11 @@ class TorchComm:
                 torch.cuda.current_stream(self.device).synchronize()      # the pack kernel of the C side has finished
                 dst_dev, src, dst = dst, src.cpu(), torch.empty(dst.shape, dtype=dst.dtype)
             nl = op.n_local
+            routes = op.relay_plan(self.group)
+            if routes is not None:
+                fin = (lambda: dst_dev.copy_(dst)) if staged else None
+                self._reqs = [_RelayExchange(op, routes, src, dst, per, self.group, fin)]
+                return 0
             ops = []
             for (peer, off, cnt, _g) in op.recv_slabs:
                 ops.append(dist.P2POp(dist.irecv, dst[(off - nl) * per:(off - nl + cnt) * per], peer, self.group))
@@ -154,6 +254,30 @@ class ShardedOperator:
         self.recv_slabs, self.send_slabs = model.shard_slabs()
         self._halo = {}
         self._comm = None
+        self._routes = None               # two-hop routes of the halo messages (SD_RELAY=1, popcount-cell ownership, >= 3 ranks)
+
+    def relay_plan(self, group=None):
+        """Routes of relay_routes for this operator's exchange, or None: built once, collectively, from every rank's receive
+        list (one message per (owner, receiver) pair in class mode)."""
+        import os
+        if self._routes is None:
+            self._routes = False
+            if os.environ.get("SD_RELAY", "0") not in ("", "0") and self.mode == "class" and self.world >= 3 \
+                    and self._exchange_fn is None:
+                import torch.distributed as dist
+                mine = [(int(peer), int(cnt)) for (peer, off, cnt, _g) in self.recv_slabs]
+                if len({pr for pr, _c in mine}) != len(mine):
+                    mine = None                      # several slabs per pair (not the case in class mode): no relays
+                everyone = [None] * self.world
+                dist.all_gather_object(everyone, mine, group=group)
+                if any(lst is None for lst in everyone):
+                    return None
+                M = {(o, r): cnt for r, lst in enumerate(everyone) for (o, cnt) in lst}
+                routes = relay_routes(M, int(os.environ.get("SD_RELAY_CHUNKS", "8")), int(os.environ.get("SD_RELAY_MIN", "65536")),
+                                      force=os.environ.get("SD_RELAY") == "2")
+                if any(k >= 0 for lst in routes.values() for (k, _lo, _hi) in lst):
+                    self._routes = routes
+        return self._routes or None
 
     def comm(self, device, group=None):
         """The communicator handed to the C recursion-level entry points: RCCL itself with SD_COMM=rccl, else
@@ -239,6 +363,11 @@ class ShardedOperator:
             # so the messages go through host copies.  The production backend is "nccl" (= RCCL), device to device.
             src_dev, dst_dev = src, dst
             src, dst = src.cpu(), torch.empty(dst.shape, dtype=dst.dtype)
+        routes = self.relay_plan(group)
+        if routes is not None:
+            per = 2 if out.is_complex() else 1
+            fin = (lambda: dst_dev.copy_(dst)) if staged else None
+            return halo, [_RelayExchange(self, routes, src.reshape(-1), dst.reshape(-1), per, group, fin)]
         ops = []
         for (peer, off, cnt, _g) in self.recv_slabs:          # recv offsets are counted from the start of [owned | halo]
             ops.append(dist.P2POp(dist.irecv, dst[off - nl:off - nl + cnt], peer, group))

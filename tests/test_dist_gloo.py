@@ -20,10 +20,12 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, L, nup, mode, q):
+def _worker(rank, world, port, L, nup, mode, q, relay=False):
     try:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                           SD_SUFFIX_BITS="6")
+        if relay:                                            # two-hop routes for every message, however small
+            os.environ.update(SD_RELAY="2", SD_RELAY_MIN="0", SD_RELAY_CHUNKS="4")
         sys.path.insert(0, ROOT)
         import torch
         import torch.distributed as dist
@@ -61,12 +63,14 @@ def _worker(rank, world, port, L, nup, mode, q):
         ok = ok and abs(nrm - float(np.linalg.norm(psi))) <= 1e-12 * float(np.linalg.norm(psi))
         d = op.dot(buf, 2j * buf)                          # conjugate-linear in the first argument, summed over ranks
         ok = bool(ok and abs(d - 2j * np.vdot(psi, psi)) <= 1e-12 * abs(np.vdot(psi, psi)))
+        routes = op.relay_plan()
+        n_relayed = 0 if routes is None else sum(hi - lo for lst in routes.values() for (k, lo, hi) in lst if k >= 0)
         dist.barrier()
         dist.destroy_process_group()
-        q.put((rank, ok, op.n_local, op.n_halo, nrm, float(np.linalg.norm(psi))))
+        q.put((rank, ok, op.n_local, op.n_halo, nrm, float(np.linalg.norm(psi)), n_relayed))
     except Exception as e:  # pragma: no cover
         import traceback
-        q.put((rank, False, repr(e) + traceback.format_exc(), 0, None, 0.0))
+        q.put((rank, False, repr(e) + traceback.format_exc(), 0, None, 0.0, 0))
 
 
 @pytest.mark.parametrize("world,L,nup,mode", [(2, 12, 6, "range"), (3, 13, 5, "range"), (2, 14, 7, "class"), (3, 14, 6, "class")])
@@ -83,3 +87,22 @@ def test_halo_exchange_gloo(world, L, nup, mode):
         p.join(timeout=60)
     assert all(r[1] is True for r in res), res
     assert sum(r[2] for r in res) > 0 and any(r[3] > 0 for r in res)
+
+
+@pytest.mark.parametrize("world,L,nup", [(3, 14, 6), (4, 16, 8)])
+def test_halo_exchange_with_two_hop_relays_gloo(world, L, nup):
+    """SD_RELAY=1: the pieces of every halo message travel either directly or owner -> relay -> receiver (dist.relay_routes,
+    the routing simulated in profiles/relay_sim.py); the halo must come out exactly as with direct messages."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, L, nup, "class", q, True)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] is True for r in res), res
+    assert all(r[6] > 0 for r in res), res          # relays were planned (the same plan on every rank)
+    assert len({r[6] for r in res}) == 1

@@ -205,10 +205,12 @@ def test_sharded_lanczos_bounds_and_kpm_without_explicit_rescaling(pkg, O, monke
     assert np.isfinite(S).all() and np.abs(S - S2).max() <= 1e-6 * max(1.0, np.abs(S2).max())   # bounds agree to 1e-8, not to the bit
 
 
-def test_sharded_drivers_three_processes_one_gpu():
+@pytest.mark.parametrize("relay", [False, True])
+def test_sharded_drivers_three_processes_one_gpu(relay):
     """Every sharded driver (apply with the overlapped exchange, Chebyshev pairs, KPM moments both ways, Lanczos bounds,
     S(q,w)) with three real processes sharing this GPU, in both ownership modes; gloo carries the halo messages through the
-    host (dist.py stages them), which exercises the same request / wait / part-1 / part-2 sequence as RCCL does."""
+    host (dist.py stages them), which exercises the same request / wait / part-1 / part-2 sequence as RCCL does.
+    relay=True: the halo messages of the popcount-cell mode take the two-hop routes of dist.relay_routes (SD_RELAY=1)."""
     import os
     import socket
     import subprocess
@@ -220,9 +222,12 @@ def test_sharded_drivers_three_processes_one_gpu():
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3",
                         "--master-addr", "127.0.0.1", "--master-port", str(port),
                         os.path.join(root, "profiles", "sharded_rehearsal.py")],
-                       cwd=root, capture_output=True, text=True, timeout=400)
+                       cwd=root, capture_output=True, text=True, timeout=400,
+                       env=dict(os.environ, **({"SD_RELAY": "2", "SD_RELAY_MIN": "0", "SD_RELAY_CHUNKS": "4"} if relay else {})))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert r.stdout.count("sharded == single: True") == 6
+    if relay:
+        assert "relayed elements per exchange:" in r.stdout
 
 
 def test_rccl_communicator_selftest_one_rank(pkg):
