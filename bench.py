@@ -239,7 +239,8 @@ def main():
             "config": {"workload": "XXZChain(L=%d, nup=%d) open, Jxy=Jz=1, hz=0: out <- H psi, ComplexF64, N=%d; "
                                    "%s shards, %d rank(s), halo exchange per step" % (L, nup, N, "popcount-cell" if op.mode == "class" else "basis-index-range", world),
                        "rows_per_rank": op.n_local, "halo_rows_rank0": op.n_halo, "shard_mode": op.mode,
-                       "device_path": model.device_path},
+                       "device_path": model.device_path,
+                       "halo_routing": "two-hop relays (SD_RELAY)" if (world > 1 and op.relay_plan() is not None) else "direct"},
             "selfcheck": check,
             "achieved_hbm_GBs_per_gpu": achieved,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
