@@ -56,3 +56,21 @@ for L in Ls:
             for r in range(P):
                 print(f"| {r} | " + " | ".join(f"{M[r, q] / 1e9:.3f}" if M[r, q] else "·" for q in range(P)) + " |")
             print("", flush=True)
+            if mode == "class" and P >= 3:
+                # the two-hop routing the exchange uses with SD_RELAY=1 (dist.relay_routes), rounds in sequence
+                dmod = sys.modules[pkg.__name__ + ".dist"]
+                Mel = {(q, r): int(M[r, q] // ES) for r in range(P) for q in range(P) if M[r, q] > 0}
+                routes = dmod.relay_routes(Mel, 8, 65536)
+                l1, l2 = {}, {}
+                for (o, r), lst in routes.items():
+                    for (k, lo, hi) in lst:
+                        if k < 0:
+                            l1[(o, r)] = l1.get((o, r), 0) + hi - lo
+                        else:
+                            l1[(o, k)] = l1.get((o, k), 0) + hi - lo
+                            l2[(k, r)] = l2.get((k, r), 0) + hi - lo
+                b1, b2 = max(l1.values()) * ES / 1e9, max(l2.values(), default=0) * ES / 1e9
+                wire = (sum(l1.values()) + sum(l2.values())) / max(1, sum(Mel.values()))
+                print(f"two-hop relays (`SD_RELAY=1`, 8 pieces per message, rounds in sequence): busiest link {busiest / 1e9:.3f} GB -> "
+                      f"{b1:.3f} + {b2:.3f} = {b1 + b2:.3f} GB ({'kept direct: no gain' if b2 == 0 else f'{(1 - (b1 + b2) * 1e9 / busiest) * 100:.0f} % less'}); "
+                      f"bytes on the wire x{wire:.2f}\n", flush=True)
