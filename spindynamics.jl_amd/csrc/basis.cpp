@@ -770,6 +770,27 @@ int sd_upload_model(sd_model *m, std::string &err) {
       r.pad0 = r.pad1 = 0;
     }
     if ((rc = up(m, m->single_rec, &d.single_rec, err))) return rc;
+    // far-bond list of every tile, resolved on the host: the kernel's waves load their p entries with one coalesced read that
+    // depends on nothing but the block index, instead of gathering addr[P ^ bond] per lane after the tile record has arrived
+    {
+      const int p = m->p, LS = m->LS;
+      m->far_base.assign(m->single_prefix.size() * (size_t)std::max(p, 1), -1);
+      if (p >= 1 && d.nn_hops > 0)
+        for (size_t k = 0; k < m->single_prefix.size(); ++k) {
+          const uint32_t P = m->single_prefix[k];
+          int64_t *fb = m->far_base.data() + k * (size_t)p;
+          for (int b = 1; b <= p - 1; ++b)
+            if (((P >> (b - 1)) ^ (P >> b)) & 1u) fb[b - 1] = m->addr[P ^ (3u << (b - 1))];
+          const uint32_t bitp = (P >> (p - 1)) & 1u, Q = P ^ (1u << (p - 1));
+          const int t2 = m->nup - __builtin_popcount(P), t2q = m->nup - __builtin_popcount(Q);
+          if (t2q >= 0 && t2q <= LS) {
+            const int64_t len = B(m, LS, t2), nU = B(m, LS - 1, t2 - 1), nUq = B(m, LS - 1, t2q - 1);
+            const int64_t my_n = bitp ? len - nU : nU;
+            if (my_n > 0) fb[p - 1] = m->addr[Q] + (bitp ? 0 : nUq);
+          }
+        }
+      if ((rc = up(m, m->far_base, &d.far_base, err))) return rc;
+    }
     if ((rc = up(m, m->single_prefix, &d.single_prefix, err))) return rc;
     if ((rc = up(m, m->single_base, &d.single_base, err))) return rc;
   }

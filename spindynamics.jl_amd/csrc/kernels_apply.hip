@@ -116,25 +116,21 @@ __global__ __launch_bounds__(BLOCK, 4) void k_apply_tiled(sd_dev_model dm, doubl
   double my_J = 0.0;
   int my_lo = 0, my_n = len;
   if (nn > 0 && p >= 1) {
-    bool fl = false;
+    // the partner bases were resolved on the host (basis.cpp, far_base): one coalesced load per wave that needs nothing but
+    // the block index, so it is in flight together with the tile record
     const int b = lane + 1;
+    if (b <= p) { my_base = dm.far_base[(size_t)tix * (size_t)p + (size_t)lane]; my_J = dm.hop_J[b - 1]; }
+    else my_base = -1;
+    bool fl = my_base >= 0;
     if (b <= p - 1) {
-      fl = (((P >> (b - 1)) ^ (P >> b)) & 1u) && !(DIAG && (dm.dbg & 1));
-      if (fl) { my_base = dm.addr[P ^ (3u << (b - 1))]; my_J = dm.hop_J[b - 1]; }
+      fl = fl && !(DIAG && (dm.dbg & 1));
     } else if (b == p) {
       // bit p of P up:   our rows with first suffix site down (i >= nU) <-> partner rows i - nU
-      // bit p of P down: our rows with first suffix site up   (i <  nU) <-> partner rows nUq + i
+      // bit p of P down: our rows with first suffix site up   (i <  nU) <-> partner rows nUq + i (the shift is in the base)
       const uint32_t bitp = (P >> (p - 1)) & 1u;
-      const uint32_t Q = P ^ (1u << (p - 1));
-      const int t2q = dm.nup - __popc(Q);
-      if (t2q >= 0 && t2q <= LS && !(DIAG && (dm.dbg & 2))) {
-        const int nUq = (int)binom_g(dm, LS - 1, t2q - 1);
-        int64_t shift;
-        if (bitp) { my_lo = nU; my_n = len - nU; shift = 0; }
-        else { my_lo = 0; my_n = nU; shift = nUq; }
-        fl = my_n > 0;
-        if (fl) { my_base = dm.addr[Q] + shift; my_J = dm.hop_J[p - 1]; }
-      }
+      if (bitp) { my_lo = nU; my_n = len - nU; }
+      else { my_lo = 0; my_n = nU; }
+      fl = fl && !(DIAG && (dm.dbg & 2));
     }
     fmask = __ballot(fl);
   }

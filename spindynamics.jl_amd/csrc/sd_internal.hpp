@@ -100,6 +100,7 @@ struct sd_dev_model {
   const uint16_t *suf_states;    // concatenated sectors (LS, t'), t' = 0..LS
   const int32_t *suf_off;        // LS+2 offsets into suf_states
   const uint16_t *suf_rank;      // 2^LS entries: rank of sigma inside its sector
+  const int64_t *far_base;       // per processed tile (single_rec order) p entries: base of the partner tile for prefix bond b = lane+1 and, in entry p-1, of the straddling bond's partner rows; -1: no hop
   int n_singles;
   int n_interior;                // sharded plans: the first n_interior single tiles read no halo (their partners are all owned)
   int tile_off;                  // first tile of this launch (lets the interior / boundary parts run as separate launches)
@@ -133,6 +134,7 @@ struct sd_model {
   std::vector<int64_t> tile_base;
   std::vector<int64_t> addr;
   std::vector<uint16_t> suf_states, suf_rank;
+  std::vector<int64_t> far_base;
   std::vector<int32_t> suf_off;
   std::vector<sd_slab> recv_slabs, send_slabs;
   int shard_mode_req = -1;       // -1 auto (env SD_SHARD_MODE), 0 index ranges, 1 popcount cells
