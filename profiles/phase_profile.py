@@ -20,7 +20,12 @@ f = pkg.lib().sd_debug_phase_profile
 f.restype = C.c_int
 f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
 rc = f(m.ctx.h, m.h, 2, b.data_ptr(), a.data_ptr(), ph)
-names = ["prologue(meta,own issue,list)", "first far issue", "diag+LDS write+lbin", "far-bond loop", "barrier", "suffix bonds", "tile lifetime", "kernel ns"]
+# intervals between the kernel's stamps (every stamp waits for all outstanding loads, so the phases are serialised here,
+# unlike in the production kernel): 0-1 record, own rows / far-bond bases requested and arrived; 1-2 first far stream issued,
+# diagonal, own rows to LDS; 2-3 barrier + far-bond loop; 3-4 two stamps back to back (the cost of a stamp); 4-5 suffix bonds
+# (+ general bonds); 5-6 epilogue and store
+names = ["record + own rows + far-bond list", "first far issue + diagonal + LDS write", "barrier + far-bond loop", "(stamp cost)",
+         "suffix bonds (+ general bonds)", "epilogue + store", "tile lifetime", "kernel ns"]
 print("rc", rc, "L", L, "tiles", m.N, "LS", os.environ.get("SD_SUFFIX_BITS", "default"))
 for n, v in zip(names, ph):
-    print(f"  {n:32s} {v:12.0f}")
+    print(f"  {n:40s} {v:12.0f}")
