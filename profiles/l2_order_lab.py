@@ -114,12 +114,17 @@ def deal(orbs, name):
     return q
 
 
+PAIR_E = int(os.environ.get("PAIR_E", "0"))   # > 0: the two tiles related by prefix bond PAIR_E share a workgroup, that bond is an LDS read
+
+
 def events(queue):
     ev = []
     for j, P in enumerate(queue):
         t0 = j / W
         reads = [(-1, (P, 0), n_up_first(P) * 16), (-1, (P, 1), (tile_len(P) - n_up_first(P)) * 16)]
         for b in range(1, p):
+            if b == PAIR_E:
+                continue
             if ((P >> (b - 1)) ^ (P >> b)) & 1:
                 Q = P ^ (3 << (b - 1))
                 reads.append((b, (Q, 0), n_up_first(Q) * 16))
