@@ -347,7 +347,7 @@ def test_lanczos_tridiag_breakdown_is_applied_after_the_queued_recursion(pkg, O,
 
 
 def test_long_queued_lanczos_stops_soon_after_a_breakdown(pkg):
-    """A breakdown at step 1 with lanc_m = 500: the queued recursion looks at the betas every 32 steps and stops; the result
+    """A breakdown at step 1 with lanc_m = 12000 (capped at N = 12870): the queued recursion looks at the betas every 32 steps and stops; the result
     is the reference's (alpha = [E], m_eff = 1) and the call does not run 500 garbage steps (wall time bound)."""
     import time
     L, nup = 16, 8
@@ -355,10 +355,10 @@ def test_long_queued_lanczos_stops_soon_after_a_breakdown(pkg):
     v = np.ones(m.N, dtype=complex)
     pkg.lanczos_tridiag(pkg.apply_H, m, v, lanc_m=4)
     t0 = time.time()
-    al, be, _ = pkg.lanczos_tridiag(pkg.apply_H, m, v, lanc_m=5000)
+    al, be, _ = pkg.lanczos_tridiag(pkg.apply_H, m, v, lanc_m=12000)
     dt = time.time() - t0
     assert len(al) == 1 and abs(al[0] - (L - 1) / 4) < 1e-13
-    assert dt < 0.05                                  # 5000 queued steps would take ~0.1 s even at 20 us each
+    assert dt < 0.12                                  # 12000 queued steps would take ~0.25 s even at 20 us each; 32 take ~1 ms
     lo, hi = pkg.lanczos_extremal(pkg.apply_H, m, lanc_m=300, psi0=v)
     assert abs(lo - (L - 1) / 4) < 1e-13 and abs(hi - (L - 1) / 4) < 1e-13
 
