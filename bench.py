@@ -3,7 +3,7 @@
 on N MI355X GPUs of one node, the state sharded over the ranks for N > 1 (popcount-cell ownership by default,
 SD_SHARD_MODE=range for contiguous basis-index ranges).
 
-  python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W          (N > 1: starts its own N ranks, see self_launch)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
@@ -36,6 +36,49 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: this process -- which never touches a GPU and never imports torch --
+    starts N ranks of this very script under torch.distributed.run on a free local port, passes their output through and
+    exits with the launcher's status (non-zero when any rank failed)."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # dmabuf IPC: what RCCL needs on this image
+    env.setdefault("OMP_NUM_THREADS", "1")
+    sys.stderr.write("bench.py: starting %d ranks: %s\n" % (n, " ".join(cmd)))
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
+    for ln in proc.stdout:            # rank 0's JSON line (and nothing else) arrives on stdout
+        sys.stdout.write(ln)
+        sys.stdout.flush()
+    raise SystemExit(proc.wait())
+
+
+def host_cores():
+    """Cores this process may really use: the scheduler affinity mask and the cgroup CPU quota, both reported."""
+    aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    quota = float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0])
+                if q > 0:
+                    quota = q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            break
+        except Exception:
+            continue
+    use = aff if quota is None else max(1, min(aff, int(quota + 0.5)))
+    return use, aff, quota
+
+
 def cpu_baseline(L, nup, budget_s=20.0):
     """The C oracle (a port of the reference's algorithm: states[] + hash map, row-owner gather; Julia is absent on the
     box) timed on the host cores on a bounded sample: the same model family at L=28, scaled to
@@ -44,8 +87,9 @@ def cpu_baseline(L, nup, budget_s=20.0):
     from oracle import oracle as O
     from math import comb
     Ls = int(os.environ.get("SD_BENCH_CPU_L", "28"))
-    # the GPU box gives one GPU a 16-core CPU share; more OpenMP threads than that only oversubscribe
-    ncores = int(os.environ.get("SD_BENCH_CPU_THREADS", str(min(16, os.cpu_count() or 1))))
+    # threads = what this process is really allowed: min(affinity mask, cgroup CPU quota); SD_BENCH_CPU_THREADS overrides
+    use, aff, quota = host_cores()
+    ncores = int(os.environ.get("SD_BENCH_CPU_THREADS", str(use)))
     O.set_num_threads(ncores)
     note = ""
     while True:
@@ -74,13 +118,85 @@ def cpu_baseline(L, nup, budget_s=20.0):
         "value": rows_per_s / n_full,
         "unit": "matvecs/s (L=32-equivalent, rows/s scaled by N)",
         "cores": O.num_threads(),
-        "host_cpu_count": os.cpu_count(),
+        "host_cpu_count": os.cpu_count(), "sched_affinity": aff, "cgroup_cpu_quota": quota,
         "kind": "port",
         "sample": f"oracle so_apply_H, XXZChain(L={Ls},nup={Ls // 2}) c128, N={m.N}, {reps} applies, "
-                  f"{dt * 1e3:.1f} ms each ({rows_per_s / 1e6:.1f} Mrows/s) on {O.num_threads()} of {os.cpu_count()} host "
-                  f"cores; basis+hash build {build_s:.1f} s; extrapolated proportional to N (optimistic for the CPU: its "
+                  f"{dt * 1e3:.1f} ms each ({rows_per_s / 1e6:.1f} Mrows/s) on {O.num_threads()} OpenMP threads (host has "
+                  f"{os.cpu_count()} cores, affinity mask {aff}, cgroup quota {quota}); basis+hash build {build_s:.1f} s; extrapolated proportional to N (optimistic for the CPU: its "
                   f"hash map leaves cache at L=32){note}",
     }
+
+
+def kernel_name(device_path, dtype):
+    """The kernel the apply of this model runs (csrc/kernels_apply.hip, sd_launch_apply), from the plan the library built."""
+    t = "<c128>" if dtype == "c128" else "<f64>"
+    if device_path == "tiled":
+        return "k_apply_tiled" + t + " (one launch per tile length class; all of them timed and counted together)"
+    if device_path == "full-tiled":
+        return "k_apply_fulltile" + t
+    return "k_apply_generic" + t
+
+
+def c_rccl_path(pkg, op, src, dst, steps, dist, backend, dev, rank, all_ok, on_timeout):
+    """The same steps once more through sd_apply_sharded on the library's own RCCL communicator (csrc/comm.cpp: pack,
+    grouped ncclSend/ncclRecv on a second stream, interior tiles meanwhile, boundary tiles after the halo) instead of
+    torch.distributed issued from Python.  Returns ms per step, or a string saying why there is no number.  If RCCL never
+    returns, a watchdog calls on_timeout() -- rank 0 prints the headline line without this figure -- and ends the process."""
+    import ctypes as C
+    import threading
+    import torch
+    if backend != "nccl":
+        return "not run: backend %s (the ranks share one GPU; RCCL needs one GPU per rank)" % backend
+    limit = float(os.environ.get("SD_BENCH_RCCL_TIMEOUT", "120"))
+    done = threading.Event()
+
+    def watchdog():
+        if not done.wait(limit):
+            sys.stderr.write("rank %d: the C RCCL path did not finish within %.0f s; giving up on it\n" % (rank, limit))
+            sys.stderr.flush()
+            on_timeout()
+            os._exit(0)
+    comm = None
+    try:
+        from spindynamics_jl_amd.dist import RcclComm
+        th = threading.Thread(target=watchdog, daemon=True)
+        th.start()
+        comm = RcclComm(op, dev)
+        m = op.model
+        lib = pkg.lib()
+        code = 2 if src.is_complex() else 1
+        m.ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+        pkg.check(lib.sd_comm_selftest(m.ctx.h, comm.h), m.ctx.h)
+        ref = torch.empty_like(dst)
+        op.apply(ref, src)
+        pkg.check(lib.sd_apply_sharded(m.ctx.h, m.h, comm.h, code, dst.data_ptr(), src.data_ptr(), op.n_local, 1), m.ctx.h)
+        torch.cuda.synchronize()
+        same = bool(torch.equal(ref, dst))
+        del ref
+        if not all_ok(same):
+            return "ran, but its result differs from the torch.distributed path: not timed"
+        dist.barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        x, y = src, dst
+        for _ in range(steps):
+            pkg.check(lib.sd_apply_sharded(m.ctx.h, m.h, comm.h, code, y.data_ptr(), x.data_ptr(), op.n_local, 1), m.ctx.h)
+            x, y = y, x
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / steps
+        t = torch.tensor([ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+    except Exception as e:     # noqa: BLE001 -- a diagnostic leg: never a reason to lose the headline
+        return "failed: %r" % (e,)
+    finally:
+        done.set()
+        if comm is not None:
+            try:
+                comm.close()
+            except Exception:
+                pass
 
 
 def main():
@@ -93,6 +209,9 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args.gpus)        # does not return
+
     import torch
     import __graft_entry__ as g
     pkg = g.load_package()
@@ -101,8 +220,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d: the launcher's world size is used\n" % (args.gpus, world))
     backend = os.environ.get("SD_BENCH_BACKEND", "nccl")   # "gloo": rehearsal of the N>1 control flow on a 1-GPU box
     if backend != "nccl":
         local_rank %= max(1, torch.cuda.device_count())
@@ -126,43 +244,105 @@ def main():
     a = op.empty(tdtype, dev)
     b = op.empty(tdtype, dev)
 
+    red_dev = dev if backend == "nccl" else "cpu"
+
+    def all_ok(flag):
+        """min over the ranks of a local 0/1 flag: every rank takes the same branch afterwards"""
+        if dist is None:
+            return bool(flag)
+        t = torch.tensor([1.0 if flag else 0.0], device=red_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item() == 1.0)
+
     def selfcheck():
         """Exact, size-independent check of the path that is about to be timed (incl. the RCCL exchange): for the
         Heisenberg point of the open chain H|F> = (L-1)/4 |F> holds bit for bit for the uniform vector |F>
-        (all partial sums are small dyadic rationals), on every row of every rank."""
-        a.fill_(1.0)
-        b.zero_()
-        op.apply(b, a)
-        ok = torch.tensor([1.0 if bool((b == (L - 1) / 4).all()) else 0.0], device=dev if backend == "nccl" else "cpu")
-        if dist is not None:
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        return bool(ok.item() == 1.0)
-
-    def checked_ok():
-        """selfcheck(); an exception on the default path (raised identically on every rank, e.g. by the plan or the host
-        logic) counts as a failed check, so that the simpler path below still gets its turn"""
+        (all partial sums are small dyadic rationals), on every row of every rank.  A rank whose check raises still
+        takes part in the reduction, so no rank is left waiting in a collective while another runs the fallback."""
+        ok = False
         try:
-            return selfcheck()
-        except Exception as e:             # noqa: BLE001 -- reported, then the fallback runs
+            a.fill_(1.0)
+            b.zero_()
+            op.apply(b, a)
+            ok = bool((b == (L - 1) / 4).all())
+        except Exception as e:             # noqa: BLE001 -- reported, then every rank runs the fallback together
             sys.stderr.write("rank %d: self-check raised %r\n" % (rank, e))
-            return False
+        return all_ok(ok)
+
+    def selfcheck_vs_unsharded():
+        """N > 1: the sharded apply of the counter-based random vector (keyed by the global index, identical for every
+        sharding) against the unsharded apply of the same vector on this rank's own GPU, owned rows compared bit for
+        bit.  Unlike the uniform state this sees a halo row that arrived in the wrong place."""
+        ok = False
+        try:
+            ref_model = pkg.XXZChain(L, nup=nup)
+            ref_op = pkg.ShardedOperator(ref_model, 0, 1)
+            x = ref_op.fill_randn(ref_op.empty(tdtype, dev), SEED)
+            y = torch.empty_like(x)
+            ref_op.apply(y, x)
+            lb, gb, ln = model.local_tiles()
+            if len(ln):
+                lens = torch.from_numpy(ln.astype("int64")).to(dev)
+                starts = torch.from_numpy(gb - lb).to(dev)               # global row = local row + (gb - lb) of its tile
+                order = torch.from_numpy(lb).to(dev).argsort()
+                rows = torch.arange(op.n_local, device=dev) + torch.repeat_interleave(starts[order], lens[order])
+                op.fill_randn(a, SEED)
+                b.zero_()
+                op.apply(b, a)
+                ok = bool(torch.equal(a, x[rows])) and bool(torch.equal(b, y[rows]))
+                del rows
+            else:
+                ok = True
+            del x, y, ref_op, ref_model
+            torch.cuda.empty_cache()
+        except Exception as e:             # noqa: BLE001
+            sys.stderr.write("rank %d: unsharded cross-check raised %r\n" % (rank, e))
+        return all_ok(ok)
+
+    def relay_selfcheck():
+        """Relays on (SD_RELAY): the halo that arrives over the two-hop routes must equal, bit for bit, the halo of the
+        direct exchange of the same vector; otherwise the routes are dropped on every rank."""
+        routes = op.relay_plan()
+        if routes is None:
+            return "direct"
+        ok = False
+        try:
+            op.fill_randn(a, SEED)
+            h1 = op.exchange(a).clone()
+            saved, op._routes = op._routes, False
+            h2 = op.exchange(a).clone()
+            op._routes = saved
+            ok = bool(torch.equal(h1, h2))
+        except Exception as e:             # noqa: BLE001
+            sys.stderr.write("rank %d: relay self-check raised %r\n" % (rank, e))
+        if all_ok(ok):
+            return "two-hop relays (SD_RELAY), halo identical to the direct exchange"
+        op._routes = False
+        return "direct (relay routes FAILED their self-check and were dropped)"
 
     check = "uniform state exact eigenvector on all ranks"
     if os.environ.get("SD_DEBUG_SKIP", "0") not in ("", "0"):
         check = "SKIPPED: SD_DEBUG_SKIP timing ablation (results are wrong by construction)"
-    elif not checked_ok():
-        # fall back to the simplest distributed path before giving up: index ranges, no overlap
-        if world > 1 and op.mode == "class":
-            model = pkg.XXZChain(L, nup=nup)
-            op = pkg.ShardedOperator(model, rank, world, mode="range")
-            op.overlap = False
-            a = op.empty(tdtype, dev)
-            b = op.empty(tdtype, dev)
-            check = "FELL BACK to index ranges without overlap (popcount-cell path failed its self-check)"
-            if not selfcheck():
-                raise SystemExit("sharded apply failed its exactness self-check on rank %d" % rank)
-        else:
-            raise SystemExit("apply failed its exactness self-check on rank %d" % rank)
+    else:
+        good = selfcheck()
+        if good and world > 1:
+            good = selfcheck_vs_unsharded()
+            check += "; owned rows of the random vector's sharded apply == unsharded apply, bit for bit"
+        if not good:
+            # fall back to the simplest distributed path before giving up: index ranges, no overlap, no relays
+            if world > 1 and op.mode == "class":
+                os.environ["SD_RELAY"] = "0"
+                model = pkg.XXZChain(L, nup=nup)
+                op = pkg.ShardedOperator(model, rank, world, mode="range")
+                op.overlap = False
+                a = op.empty(tdtype, dev)
+                b = op.empty(tdtype, dev)
+                check = "FELL BACK to index ranges without overlap (popcount-cell path failed its self-check)"
+                if not (selfcheck() and selfcheck_vs_unsharded()):
+                    raise SystemExit("sharded apply failed its exactness self-check on rank %d" % rank)
+            else:
+                raise SystemExit("apply failed its exactness self-check on rank %d" % rank)
+    halo_routing = relay_selfcheck() if world > 1 else "none (one rank)"
     op.fill_randn(a, SEED)
     nrm = op.norm(a)
     a /= nrm
@@ -210,6 +390,18 @@ def main():
         torch.cuda.synchronize()
         kern_ms = e0.elapsed_time(e1) / args.steps
 
+    # ---- N > 1: where a step's time goes on every rank, and the same steps through the library's own RCCL path ----
+    per_rank, c_rccl = None, None
+    if world > 1:
+        prof = [op.apply_profiled(dst, src) for _ in range(3)][-1]
+        prof["rank"] = rank
+        prof["rows_owned"], prof["rows_imported"] = op.n_local, op.n_halo
+        prof["bytes_sent_per_peer"] = {str(peer): cnt * esize for (peer, _off, cnt, _g) in op.send_slabs}
+        prof["bytes_recv_per_peer"] = {str(peer): cnt * esize for (peer, _off, cnt, _g) in op.recv_slabs}
+        prof["kernel_only"] = kern_ms
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, prof)
+
     if rank == 0:
         N = model.N
         ms_per_step = elapsed / args.steps * 1e3
@@ -249,16 +441,26 @@ def main():
                                    "%s shards, %d rank(s), halo exchange per step" % (L, nup, N, "popcount-cell" if op.mode == "class" else "basis-index-range", world),
                        "rows_per_rank": op.n_local, "halo_rows_rank0": op.n_halo, "shard_mode": op.mode,
                        "device_path": model.device_path,
-                       "halo_routing": "two-hop relays (SD_RELAY)" if (world > 1 and op.relay_plan() is not None) else "direct"},
+                       "halo_routing": halo_routing, "per_rank_ms": per_rank, "c_rccl_path_ms": c_rccl},
             "selfcheck": check,
             "achieved_hbm_GBs_per_gpu": achieved,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "frac_of_copy_ceiling": achieved / HBM_COPY_GBS,
                          "traffic": traffic, "traffic_source": traffic_source,
-                         "kernel": ("k_apply_tiled<c128>" if args.dtype == "c128" else "k_apply_tiled<f64>")
-                                   + " (one launch per tile length class; all of them timed and counted together)",
+                         "kernel": kernel_name(model.device_path, args.dtype),
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes},
         }
+    else:
+        line = None
+    if world > 1:
+        def on_timeout():
+            if rank == 0:
+                line["config"]["c_rccl_path_ms"] = "timeout: RCCL did not return (SD_BENCH_RCCL_TIMEOUT)"
+                print(json.dumps(line), flush=True)
+        c_rccl = c_rccl_path(pkg, op, src, dst, args.steps, dist, backend, dev, rank, all_ok, on_timeout)
+        if rank == 0:
+            line["config"]["c_rccl_path_ms"] = c_rccl
+    if rank == 0:
         if world == 1 and not args.no_cpu:
             try:
                 line["cpu_baseline"] = cpu_baseline(L, nup)

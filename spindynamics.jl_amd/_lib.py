@@ -211,6 +211,7 @@ class Context:
         self.h = _vp()
         check(lib().sd_ctx_create(device, C.byref(self.h)))
         self.device = device
+        self.kpm_doubling = True      # mirror of the library's per-context flag (sd_ctx_set_kpm_doubling)
 
     def set_stream(self, stream_ptr):
         check(lib().sd_ctx_set_stream(self.h, _vp(stream_ptr)), self.h)
@@ -218,6 +219,7 @@ class Context:
     def set_kpm_doubling(self, on):
         """True (default): two Chebyshev moments per apply; False: the reference's one-moment-per-apply loop."""
         check(lib().sd_ctx_set_kpm_doubling(self.h, 1 if on else 0), self.h)
+        self.kpm_doubling = bool(on)
 
     def release_scratch(self):
         """Free the staging buffers kept between host-pointer apply calls (re-created on demand)."""

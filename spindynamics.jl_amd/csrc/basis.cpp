@@ -151,10 +151,12 @@ static void xcd_order(const sd_model *m, int p, std::vector<uint32_t> &tp_io, st
     if (FO > 8) FO = 8;
     int CH = 32;
     if (const char *e = getenv("SD_XCD_CHUNK")) CH = atoi(e);
+    int B0 = 1;     // first bond considered as an orbit generator (two-pass probe: the bonds below belong to the other pass)
+    if (const char *e = getenv("SD_XCD_ORBIT_FROM")) B0 = std::max(1, atoi(e));
     const size_t nt = tp_io.size();
     auto first_seen_reset = [&](uint32_t P) {
       uint32_t C0 = P; int ng = 0;
-      for (int b = 1; b + 1 <= p && ng < FO; b += 2)
+      for (int b = B0; b + 1 <= p && ng < FO; b += 2)
         if (((P >> (b - 1)) ^ (P >> b)) & 1u) {
           if (!((P >> (b - 1)) & 1u)) C0 ^= 3u << (b - 1);
           ++ng;
@@ -168,7 +170,7 @@ static void xcd_order(const sd_model *m, int p, std::vector<uint32_t> &tp_io, st
       for (size_t k = 0; k < nt; ++k) {
         const uint32_t P = tp_io[k];
         uint32_t C0 = P; int member = 0, ng = 0;
-        for (int b = 1; b + 1 <= p && ng < FO; b += 2)
+        for (int b = B0; b + 1 <= p && ng < FO; b += 2)
           if (((P >> (b - 1)) ^ (P >> b)) & 1u) {
             if (!((P >> (b - 1)) & 1u)) { C0 ^= 3u << (b - 1); member |= 1 << ng; }
             ++ng;

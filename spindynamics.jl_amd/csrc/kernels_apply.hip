@@ -123,7 +123,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_apply_tiled(sd_dev_model dm, doubl
     else my_base = -1;
     bool fl = my_base >= 0;
     if (b <= p - 1) {
-      fl = fl && !(DIAG && (dm.dbg & 1));
+      fl = fl && !(DIAG && ((dm.dbg & 1) || b <= (dm.dbg >> 8)));      // dbg >> 8 = m: prefix bonds 1..m left to another pass (two-pass probe)
     } else if (b == p) {
       // bit p of P up:   our rows with first suffix site down (i >= nU) <-> partner rows i - nU
       // bit p of P down: our rows with first suffix site up   (i <  nU) <-> partner rows nUq + i (the shift is in the base)

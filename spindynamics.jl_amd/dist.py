@@ -426,6 +426,34 @@ class ShardedOperator:
         """out = H psi on the owned rows; the halo is refreshed first (pass exchange=False to reuse it)."""
         return self._apply(out, psi, group, 0, exchange)
 
+    def apply_profiled(self, out, psi, group=None):
+        """One overlapped apply with HIP events between its phases; returns ms of {pack, post (host time to post the
+        sends / receives), interior, exchange_wait (what the compute stream still waits for the halo after the interior
+        tiles), boundary}.  Diagnostic twin of apply(): same launches in the same order (bench.py, N > 1)."""
+        import time
+        import torch
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(7)]
+        ev[5].record()
+        if self.mode == "class" and self.world > 1 and self._exchange_fn is None:
+            self.pack(psi)                       # timed alone; exchange_start packs the same bytes again
+        ev[6].record()
+        ev[0].record()
+        t0 = time.perf_counter()
+        halo, reqs = self.exchange_start(psi, group)
+        post_ms = (time.perf_counter() - t0) * 1e3
+        ev[1].record()
+        self._launch(out, psi, halo, 0, part=1)
+        ev[2].record()
+        for req in reqs:
+            req.wait()
+        ev[3].record()
+        self._launch(out, psi, halo, 0, part=2)
+        ev[4].record()
+        torch.cuda.synchronize(psi.device)
+        return {"pack": ev[5].elapsed_time(ev[6]), "post_host": post_ms, "pack_and_post_on_stream": ev[0].elapsed_time(ev[1]),
+                "interior": ev[1].elapsed_time(ev[2]), "exchange_wait": ev[2].elapsed_time(ev[3]),
+                "boundary": ev[3].elapsed_time(ev[4])}
+
     def apply_rescaled(self, out, psi, a, b, group=None):
         return self._apply(out, psi, group, 1, a=a, b=b)
 
@@ -500,13 +528,14 @@ class ShardedOperator:
         if M < 2:
             raise _lib.ArgumentError("kpm_m must be >= 2")
         mu = np.zeros(int(M))
+        before = self.model.ctx.kpm_doubling          # the caller's own choice for unsharded calls is put back afterwards
         self.model.ctx.set_kpm_doubling(bool(doubling))
         try:
             phi = phi.contiguous()
             self._call(lib().sd_kpm_moments_sharded, phi, phi.data_ptr(), self.n_local, int(M), float(a), float(b),
                        mu.ctypes.data_as(C.POINTER(C.c_double)), group=group)
         finally:
-            self.model.ctx.set_kpm_doubling(True)
+            self.model.ctx.set_kpm_doubling(before)
         return mu
 
     # ---- Lanczos on a sharded state (energy bounds for the sharded KPM / Chebyshev drivers) ----

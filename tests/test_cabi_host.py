@@ -4,6 +4,7 @@ plans) agree with the oracle.  No device compute is called here."""
 import ctypes as C
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -335,3 +336,17 @@ def test_julia_ccalls_match_the_header(rel):
         assert nvals == len(targs), (rel, name, "values passed", nvals, "declared", len(targs))
     # a ccall whose name is not a literal cannot be compiled by Julia
     assert not re.search(r"ccall\(\((?!:)[A-Za-z_]", open(os.path.join(ROOT, rel)).read())
+
+
+def test_bench_gpus_n_launches_ranks_itself():
+    """bench.py --gpus 2 without a launcher must start its own ranks (the driver calls it exactly so for N = 1, and the
+    scaling runs must not die on a usage message).  Without a GPU the ranks fail, which the parent reports as its status."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--L", "12", "--steps", "1", "--warmup", "0",
+                        "--no-cpu"], cwd=ROOT, capture_output=True, text=True, timeout=300, env=env)
+    assert "starting 2 ranks" in r.stderr, r.stderr[-2000:]
+    assert "launch with torch.distributed.run" not in r.stderr + r.stdout
+    import torch
+    if not torch.cuda.is_available():
+        assert r.returncode != 0          # the ranks could not create a context: the parent hands that on

@@ -254,3 +254,30 @@ def test_rccl_communicator_selftest_one_rank(pkg):
         assert torch.equal(out, out2)
     finally:
         pkg.lib().sd_comm_destroy(h)
+
+
+def test_bench_starts_its_own_ranks_two_processes_one_gpu():
+    """`python bench.py --gpus 2` from a plain invocation (no launcher, WORLD_SIZE unset): the parent starts two ranks under
+    torch.distributed.run, relays rank 0's single JSON line and exits 0.  gloo backend: both ranks share this GPU (the
+    N > 1 control flow -- self-checks, overlapped exchange, per-rank breakdown -- is the one RCCL runs)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["SD_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--L", "24", "--steps", "5",
+                        "--warmup", "1"], cwd=root, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 5 and line["value"] > 0
+    assert "bit for bit" in line["selfcheck"] and "FELL BACK" not in line["selfcheck"]
+    per_rank = line["config"]["per_rank_ms"]
+    assert [p["rank"] for p in per_rank] == [0, 1]
+    for p in per_rank:
+        assert set(("pack", "interior", "exchange_wait", "boundary", "bytes_sent_per_peer")) <= set(p)
+    assert sum(p["rows_owned"] for p in per_rank) == 2704156          # C(24, 12)
+    assert str(line["config"]["c_rccl_path_ms"]).startswith("not run")   # two ranks on one GPU: RCCL cannot run
