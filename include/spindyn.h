@@ -18,8 +18,9 @@
  *  - basis indices are 0-based at this ABI (reference index = idx0 + 1).
  *  - "host" pointers are caller-owned host memory, only touched during the call.
  *    "dev" pointers are device (HIP) pointers on the context's device.
- *  - a sd_model is immutable after creation and may be shared between threads;
- *    a sd_ctx (device + stream + scratch) must not be used concurrently.
+ *  - a sd_model is immutable once set up -- creation, then at most one sd_model_set_shard[_mode] call before any other
+ *    thread sees it -- and may then be shared between threads; everything a call may change (stream, scratch, the
+ *    kpm switches, a caller's operator) lives in the sd_ctx, which must not be used concurrently: one context per thread.
  */
 #ifndef SPINDYN_H
 #define SPINDYN_H
@@ -74,6 +75,16 @@ int sd_ctx_set_stream(sd_ctx *ctx, void *hip_stream);
  * mu_2n = 2<v_n|v_n> - mu_0, mu_2n+1 = 2Re<v_n|v_n+1> - mu_1 (v_n = T_n(H~)phi); on == 0 runs the reference's loop
  * (src/KPM_Sqw.jl:103-124), one moment <phi|v_k> per apply.  Same moments up to rounding. */
 int sd_ctx_set_kpm_doubling(sd_ctx *ctx, int on);
+/* sd_kpm_sqw / sd_kpm_sqw_sharded with a REAL psi0 (Float64, or ComplexF64 whose imaginary parts are all zero -- checked on
+ * the device): on != 0 (default) computes the moments once per pair of momenta (q, 2 pi - q) of the list and copies the row,
+ * because H is real and phi_{2pi-q} = conj(phi_q) gives the same moments; on == 0 runs every q on its own, as the reference
+ * does (src/KPM_Sqw.jl:218-252).  The copied row differs from a recomputed one by the rounding of exp(iqr) only (<= 1e-13
+ * on S).  Never used with a caller's operator (sd_ctx_set_apply_callback). */
+int sd_ctx_set_kpm_pair_q(sd_ctx *ctx, int on);
+/* Operator applications (built-in H or the caller's operator) that the recursion-level entry points have queued on this
+ * context since it was created: one per recursion step.  The difference across a call says how many steps it really ran
+ * (e.g. how soon a queued Lanczos recursion noticed a breakdown). */
+int64_t sd_ctx_apply_count(const sd_ctx *ctx);
 /* A context keeps between calls: the device staging buffers of the host-pointer operator calls (sd_apply,
  * sd_apply_rescaled: two vectors), its reduction scratch, and the work vectors of the recursion-level calls (a pool of at
  * most SD_POOL_MAX_GB = 96 GB by default: a hipMalloc/hipFree pair costs 0.3-0.6 ms whatever the size, as long as
@@ -123,16 +134,17 @@ int sd_apply_rescaled(sd_ctx *ctx, const sd_model *m, int dtype, void *out_host,
 int sd_apply_rescaled_dev(sd_ctx *ctx, const sd_model *m, int dtype, void *out_dev, const void *psi_dev,
                           int64_t n, double a, double b);
 /* The operator as a callable at the recursion level.  Every reference solver takes `applyH!` as an argument
- * (src/Lanczos.jl:27-29, src/TimeEvolution/Chebyshev.jl:61-64, src/KPM_Sqw.jl:95-98, ...).  With a callback installed,
- * every recursion entry point of this library (lanczos_*, energy_bounds, krylov / chebyshev evolve, kpm_*, *_sqw, and their
- * _dev / _sharded forms) calls fn for out <- H psi instead of the built-in kernel and applies its own fused step (rescale,
- * recurrence, dot products) in a second, elementwise pass.  fn gets DEVICE pointers of n_local elements of `dtype` and the
- * HIP stream the call must be ordered on (enqueue there, or finish before returning); out never aliases psi; a nonzero
- * return aborts the call with SD_ECOMM.  The operator-level entries (sd_apply*, sd_apply_sharded*) always run the built-in
- * operator, so fn may call them on the same model.  On a sharded model fn is responsible for its own halo exchange.
- * fn == NULL restores the built-in operator. */
+ * (src/Lanczos.jl:27-29, src/TimeEvolution/Chebyshev.jl:61-64, src/KPM_Sqw.jl:95-98, ...).  With a callback installed in a
+ * context, every recursion entry point called on THAT context (lanczos_*, energy_bounds, krylov / chebyshev evolve, kpm_*,
+ * *_sqw, and their _dev / _sharded forms) calls fn for out <- H psi instead of the built-in kernel and applies its own fused
+ * step (rescale, recurrence, dot products) in a second, elementwise pass.  fn gets DEVICE pointers of n_local elements of
+ * `dtype` and the HIP stream the call must be ordered on (enqueue there, or finish before returning); out never aliases psi;
+ * a nonzero return aborts the call with SD_ECOMM.  The operator-level entries (sd_apply*, sd_apply_sharded*) always run the
+ * built-in operator, so fn may call them -- on a sharded model sd_apply_sharded, which includes the halo exchange.
+ * fn == NULL restores the built-in operator.  The callback belongs to the context, not to the model: models stay immutable
+ * and shareable, and another thread's recursions (on its own context) are unaffected. */
 typedef int (*sd_apply_fn)(void *user, int dtype, void *out_dev, const void *psi_dev, int64_t n_local, void *hip_stream);
-int sd_model_set_apply_callback(sd_model *m, sd_apply_fn fn, void *user);
+int sd_ctx_set_apply_callback(sd_ctx *ctx, sd_apply_fn fn, void *user);
 /* Sz_q_vector   src/Hamiltonian.jl:307-337.  phi_out is always ComplexF64. */
 int sd_szq(sd_ctx *ctx, const sd_model *m, int dtype_in, const void *psi0_host, int64_t n, double q,
            void *phi_out_host);
@@ -348,8 +360,8 @@ int sd_comm_from_callbacks(const sd_comm_callbacks *cb, int rank, int nranks, sd
 int sd_comm_rccl_unique_id(void *id128);
 int sd_comm_rccl_create(sd_ctx *ctx, int rank, int nranks, const void *id128, sd_comm **out);
 void sd_comm_destroy(sd_comm *comm);
-/* Diagnostic (RCCL communicator): ncclAllReduce of two device doubles and a grouped ncclSend/ncclRecv to this rank itself,
- * bytes checked.  Needs no peer with nranks == 1; with more ranks all of them must call it. */
+/* Diagnostic (RCCL communicator): ncclAllReduce of two device doubles and a grouped ncclSend/ncclRecv round the ring of ranks
+ * (rank -> rank+1; to itself with nranks == 1), bytes checked.  Collective: with more than one rank all of them must call it. */
 int sd_comm_selftest(sd_ctx *ctx, sd_comm *comm);
 
 /* out = H psi on the owned rows, halo exchange included (overlapped with the interior tiles when overlap != 0). */

@@ -60,6 +60,9 @@ default_context() = (_ctx[] === nothing && (_ctx[] = Context()); _ctx[])
 # release of the device vectors a context keeps between calls (staging of sd_apply, pooled work vectors of the recursions).
 set_kpm_doubling!(ctx::Context, on::Bool) =
     check(ccall((:sd_ctx_set_kpm_doubling, libspindyn), Cint, (Ptr{Cvoid}, Cint), ctx.h, on ? 1 : 0), ctx.h)
+# real psi0: S(q, w) once per pair (q, 2pi - q) (default) or every q on its own as src/KPM_Sqw.jl:218-252 does
+set_kpm_pair_q!(ctx::Context, on::Bool) =
+    check(ccall((:sd_ctx_set_kpm_pair_q, libspindyn), Cint, (Ptr{Cvoid}, Cint), ctx.h, on ? 1 : 0), ctx.h)
 release_scratch!(ctx::Context) = check(ccall((:sd_ctx_release_scratch, libspindyn), Cint, (Ptr{Cvoid},), ctx.h), ctx.h)
 
 mutable struct Model

@@ -36,18 +36,28 @@ if 2 in which:
 if 3 in which:
     L = 30
     m = pkg.XXZChain(L, nup=L // 2)
-    psi0 = state(m.N, 3)
     q = pkg.momenta(m)
-    nq = int(os.environ.get("SD_CFG3_NQ", str(len(q))))
     omega = np.arange(0.0, 5.0 + 1e-9, 0.05)
     a, b = L / 2 + 1.0, 0.0            # explicit rescaling: |E| <= L/2 for the Heisenberg chain
-    t0 = time.time()
-    S = pkg.dynamical_structure_factor(m, psi0, q[:nq], omega, method="kpm", kpm_m=1024, a=a, b=b)
-    dt = time.time() - t0
-    print(json.dumps({"config": 3, "what": "dynamical_structure_factor(:kpm, kpm_m=1024), L=30, %d momenta, %d omegas" % (nq, len(omega)),
-                      "N": m.N, "seconds": dt, "seconds_per_q": dt / nq, "applies_per_q": 512,
-                      "S_finite": bool(np.isfinite(S).all()), "S_min": float(S.min()), "S_max": float(S.max())}), flush=True)
-    del psi0, S, m
+    # (i) a REAL psi0 (what groundstate() returns, the reference's own use, examples/example_kpmSqw.jl): every pair
+    #     (q, 2pi - q) of momenta(model) is computed once; (ii) a complex psi0: nothing to pair, a few momenta
+    for kind in ("real", "complex"):
+        if kind == "real":
+            psi0 = np.random.default_rng(3).standard_normal(m.N)
+            psi0 /= np.linalg.norm(psi0)
+            nq = int(os.environ.get("SD_CFG3_NQ", str(len(q))))
+        else:
+            psi0 = state(m.N, 3)
+            nq = int(os.environ.get("SD_CFG3_NQ_COMPLEX", "3"))
+        t0 = time.time()
+        S = pkg.dynamical_structure_factor(m, psi0, q[:nq], omega, method="kpm", kpm_m=1024, a=a, b=b)
+        dt = time.time() - t0
+        print(json.dumps({"config": 3, "what": "dynamical_structure_factor(:kpm, kpm_m=1024), L=30, %s psi0, %d momenta, %d omegas"
+                                               % (kind, nq, len(omega)),
+                          "N": m.N, "seconds": dt, "seconds_per_q": dt / nq, "applies_per_computed_q": 512,
+                          "S_finite": bool(np.isfinite(S).all()), "S_min": float(S.min()), "S_max": float(S.max())}), flush=True)
+        del psi0, S
+    del m
 
 if 4 in which:
     L = 32

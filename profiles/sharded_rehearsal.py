@@ -62,6 +62,26 @@ for mode in ("class", "range"):
     S = op.kpm_sqw(mine, q, omega, a=a, b=b, kpm_m=40)
     S_ref = pkg.kpm_sqw(psi, full, q, omega, a=a, b=b, kpm_m=40)
     ok &= bool(np.abs(S - S_ref).max() <= 1e-10 * max(1.0, np.abs(S_ref).max()))
+    # a caller's operator on a SHARDED model, written to the header's contract: it forwards to the operator-level entry
+    # sd_apply_sharded (halo exchange included), which must run the built-in H and not re-enter the callback
+    calls = [0]
+    cm = op.comm(mine.device)
+
+    def forward(out_t, psi_t, model):
+        calls[0] += 1
+        if calls[0] > 1000:
+            raise RuntimeError("the callback re-entered itself")
+        code = 2 if psi_t.is_complex() else 1
+        model.ctx.set_stream(torch.cuda.current_stream(psi_t.device).cuda_stream)
+        pkg.check(pkg.lib().sd_apply_sharded(model.ctx.h, model.h, cm.h, code, out_t.data_ptr(), psi_t.data_ptr(), op.n_local, 1),
+                  model.ctx.h)
+
+    m.set_apply(forward)
+    try:
+        mu_cb = op.kpm_moments(mine, 21, a, b, doubling=False)
+    finally:
+        m.set_apply(None)
+    ok &= bool(np.abs(mu_cb - mu_ref).max() <= 1e-13) and calls[0] == 20
     sys.stdout.write("rank %d of %d mode %s n_local %d n_halo %d sharded == single: %s\n" % (rank, world, mode, op.n_local, op.n_halo, bool(ok)))
     routes = op.relay_plan()
     if routes is not None:          # SD_RELAY=1: which part of the exchange took two hops

@@ -85,6 +85,8 @@ PROTOTYPES = {
     "sd_ctx_destroy": (None, [_vp]),
     "sd_ctx_set_stream": (_i, [_vp, _vp]),
     "sd_ctx_set_kpm_doubling": (_i, [_vp, _i]),
+    "sd_ctx_set_kpm_pair_q": (_i, [_vp, _i]),
+    "sd_ctx_apply_count": (_i64, [_vp]),
     "sd_ctx_release_scratch": (_i, [_vp]),
     "sd_ctx_synchronize": (_i, [_vp]),
     "sd_last_error": (C.c_char_p, [_vp]),
@@ -140,7 +142,7 @@ PROTOTYPES = {
     "sd_apply_sharded_cheb2_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _d, _d, _d, _d, _d, _d, _vp, _vp, _i]),
     "sd_kpm_step_sharded_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _d, _d, _i, _dp]),
     "sd_comm_from_callbacks": (_i, [C.POINTER(sd_comm_callbacks), _i, _i, C.POINTER(_vp)]),
-    "sd_model_set_apply_callback": (_i, [_vp, APPLY_FN, _vp]),
+    "sd_ctx_set_apply_callback": (_i, [_vp, APPLY_FN, _vp]),
     "sd_comm_rccl_unique_id": (_i, [_vp]),
     "sd_comm_rccl_create": (_i, [_vp, _i, _i, _vp, C.POINTER(_vp)]),
     "sd_comm_destroy": (None, [_vp]),
@@ -220,6 +222,15 @@ class Context:
         """True (default): two Chebyshev moments per apply; False: the reference's one-moment-per-apply loop."""
         check(lib().sd_ctx_set_kpm_doubling(self.h, 1 if on else 0), self.h)
         self.kpm_doubling = bool(on)
+
+    def set_kpm_pair_q(self, on):
+        """True (default): kpm_sqw of a real psi0 computes each pair of momenta (q, 2 pi - q) once; False: every q on its own,
+        as the reference does."""
+        check(lib().sd_ctx_set_kpm_pair_q(self.h, 1 if on else 0), self.h)
+
+    def apply_count(self):
+        """Operator applications the recursion-level calls have queued on this context so far (one per recursion step)."""
+        return int(lib().sd_ctx_apply_count(self.h))
 
     def release_scratch(self):
         """Free the staging buffers kept between host-pointer apply calls (re-created on demand)."""

@@ -776,7 +776,11 @@ int sd_upload_model(sd_model *m, std::string &err) {
     // depends on nothing but the block index, instead of gathering addr[P ^ bond] per lane after the tile record has arrived
     {
       const int p = m->p, LS = m->LS;
-      m->far_base.assign(m->single_prefix.size() * (size_t)std::max(p, 1), -1);
+      // only where the kernel reads it (chain bonds present): with p near SD_MAX_PREFIX_BITS the table is tiles x p x 8 B on
+      // host and device, far too much to spend on a model whose hops are all general bonds
+      m->far_base.clear();
+      m->far_base.shrink_to_fit();
+      if (p >= 1 && d.nn_hops > 0) m->far_base.assign(m->single_prefix.size() * (size_t)p, -1);
       if (p >= 1 && d.nn_hops > 0)
         for (size_t k = 0; k < m->single_prefix.size(); ++k) {
           const uint32_t P = m->single_prefix[k];

@@ -183,6 +183,7 @@ void sd_ctx_destroy(sd_ctx *c) {
   if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
   if (c->d_partials) (void)hipFree(c->d_partials);
   for (void *b : c->stage) if (b) (void)hipFree(b);
+  sd_xfer_release(c);
   sd_pool_release(c);
   if (c->d_scalars) (void)hipFree(c->d_scalars);
   if (c->h_scalars) (void)hipHostFree(c->h_scalars);
@@ -205,6 +206,14 @@ int sd_ctx_set_kpm_doubling(sd_ctx *ctx, int on) {
   return SD_OK;
 }
 
+int64_t sd_ctx_apply_count(const sd_ctx *ctx) { return ctx ? ctx->n_applies : -1; }
+
+int sd_ctx_set_kpm_pair_q(sd_ctx *ctx, int on) {
+  if (!ctx) return SD_EARG;
+  ctx->kpm_pair_q = on ? 1 : 0;
+  return SD_OK;
+}
+
 int sd_ctx_release_scratch(sd_ctx *ctx) {
   if (!ctx) return SD_EARG;
   SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -214,6 +223,7 @@ int sd_ctx_release_scratch(sd_ctx *ctx) {
   }
   if (ctx->d_partials) (void)hipFree(ctx->d_partials);
   ctx->d_partials = nullptr; ctx->partials_cap = 0;
+  sd_xfer_release(ctx);
   sd_pool_release(ctx);
   return SD_OK;
 }
@@ -225,6 +235,25 @@ int sd_ctx_synchronize(sd_ctx *ctx) {
 }
 
 const char *sd_last_error(const sd_ctx *ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+
+// Plan + device tables of a model.  The plan's host tables grow with the number of tiles (up to 2^26 prefixes x p entries): a
+// failed host allocation must come back as a status, never unwind through the C ABI.
+static int plan_and_upload(sd_model *m, int rank, int nranks, std::string &err) {
+  try {
+    int rc = sd_build_plan(m, rank, nranks, err);
+    if (!rc && m->ctx) {
+      if (hipSetDevice(m->ctx->device) != hipSuccess) { rc = SD_EHIP; err = "hipSetDevice failed"; }
+      else rc = sd_upload_model(m, err);
+    }
+    return rc;
+  } catch (const std::bad_alloc &) {
+    err = "out of host memory while building the plan tables of this model";
+    return SD_ENOMEM;
+  } catch (const std::exception &e) {
+    err = std::string("plan construction failed: ") + e.what();
+    return SD_EINTERNAL;
+  }
+}
 
 int sd_model_create(sd_ctx *ctx, int L, int nup, int n_hop, const int *hop_i, const int *hop_j, const double *hop_J,
                     int n_zz, const int *zz_i, const int *zz_j, const double *zz_J, const double *field,
@@ -257,11 +286,7 @@ int sd_model_create(sd_ctx *ctx, int L, int nup, int n_hop, const int *hop_i, co
   sd_fill_binom(m->binom);
   m->N = nup < 0 ? ((int64_t)1 << L) : sd_binom(L, nup);
   std::string err;
-  int rc = sd_build_plan(m, 0, 1, err);
-  if (!rc && ctx) {
-    if (hipSetDevice(ctx->device) != hipSuccess) { rc = SD_EHIP; err = "hipSetDevice failed"; }
-    else rc = sd_upload_model(m, err);
-  }
+  int rc = plan_and_upload(m, 0, 1, err);
   if (rc) { sd_model_destroy(m); return fail(ctx, rc, err); }
   *out = m;
   return SD_OK;
@@ -290,10 +315,10 @@ void sd_model_destroy(sd_model *m) {
 int64_t sd_model_dim(const sd_model *m) { return m ? m->N : -1; }
 int sd_model_L(const sd_model *m) { return m ? m->L : -1; }
 int sd_model_nup(const sd_model *m) { return m ? m->nup : -2; }
-int sd_model_set_apply_callback(sd_model *m, sd_apply_fn fn, void *user) {
-  if (!m) return SD_EARG;
-  m->user_apply = fn;
-  m->user_apply_data = fn ? user : nullptr;
+int sd_ctx_set_apply_callback(sd_ctx *ctx, sd_apply_fn fn, void *user) {
+  if (!ctx) return SD_EARG;
+  ctx->user_apply = fn;
+  ctx->user_apply_data = fn ? user : nullptr;
   return SD_OK;
 }
 int sd_model_path(const sd_model *m) { return !m ? 0 : m->p >= 0 ? 1 : m->full_ls > 0 ? 2 : 0; }
@@ -319,11 +344,7 @@ int sd_model_set_shard_mode(sd_model *m, int rank, int nranks, int mode) {
 int sd_model_set_shard(sd_model *m, int rank, int nranks) {
   if (!m) return SD_EARG;
   std::string err;
-  int rc = sd_build_plan(m, rank, nranks, err);
-  if (!rc && m->ctx) {
-    if (hipSetDevice(m->ctx->device) != hipSuccess) { rc = SD_EHIP; err = "hipSetDevice failed"; }
-    else rc = sd_upload_model(m, err);
-  }
+  int rc = plan_and_upload(m, rank, nranks, err);
   if (rc) return fail(m->ctx, rc, err);
   return SD_OK;
 }
@@ -475,13 +496,11 @@ static int apply_host(sd_ctx *ctx, const sd_model *m, int dtype, void *out, cons
   const size_t bytes = (size_t)n * (dtype == SD_C128 ? 16 : 8);
   void *din, *dout;
   if ((rc = stage_buf(ctx, 0, bytes, &din)) || (rc = stage_buf(ctx, 1, bytes, &dout))) return rc;
-  SD_HIP(ctx, hipMemcpyAsync(din, psi, bytes, hipMemcpyHostToDevice, ctx->stream));
+  if ((rc = sd_xfer_h2d(ctx, din, psi, bytes))) return rc;
   sd_epi_args ea; ea.a = a; ea.b = b;
   rc = sd_launch_apply(ctx, m, dtype, dout, din, epi, ea);
   if (rc) return rc;
-  SD_HIP(ctx, hipMemcpyAsync(out, dout, bytes, hipMemcpyDeviceToHost, ctx->stream));
-  SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  return SD_OK;
+  return sd_xfer_d2h(ctx, out, dout, bytes);
 }
 
 int sd_apply(sd_ctx *ctx, const sd_model *m, int dtype, void *out, const void *psi, int64_t n) {
@@ -509,12 +528,10 @@ int sd_szq(sd_ctx *ctx, const sd_model *m, int dtype_in, const void *psi0, int64
   TmpDev din(ctx), dout(ctx);
   int rc;
   if ((rc = din.alloc(bin)) || (rc = dout.alloc(bout))) return rc;
-  SD_HIP(ctx, hipMemcpyAsync(din.p, psi0, bin, hipMemcpyHostToDevice, ctx->stream));
+  if ((rc = sd_xfer_h2d(ctx, din.p, psi0, bin))) return rc;
   rc = sd_launch_szq(ctx, m, dtype_in, din.p, q, dout.p);
   if (rc) return rc;
-  SD_HIP(ctx, hipMemcpyAsync(phi, dout.p, bout, hipMemcpyDeviceToHost, ctx->stream));
-  SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  return SD_OK;
+  return sd_xfer_d2h(ctx, phi, dout.p, bout);
 }
 
 int sd_bench_apply_dev(sd_ctx *ctx, const sd_model *m, int dtype, void *buf_a, void *buf_b, int64_t n, int reps,
@@ -608,7 +625,7 @@ static int obs_host(sd_ctx *ctx, const sd_model *m, int dtype, const void *psi, 
   TmpDev d(ctx);
   int rc = d.alloc(bytes);
   if (rc) return rc;
-  SD_HIP(ctx, hipMemcpyAsync(d.p, psi, bytes, hipMemcpyHostToDevice, ctx->stream));
+  if ((rc = sd_xfer_h2d(ctx, d.p, psi, bytes))) return rc;
   return obs_dev(ctx, m, dtype, d.p, n, what, out, q_out);
 }
 
@@ -650,12 +667,10 @@ int sd_spin_operator(sd_ctx *ctx, const sd_model *m, int dtype, int site, int op
   TmpDev din(ctx), dout(ctx);
   int rc;
   if ((rc = din.alloc(bin)) || (rc = dout.alloc(bout))) return rc;
-  SD_HIP(ctx, hipMemcpyAsync(din.p, psi_host, bin, hipMemcpyHostToDevice, ctx->stream));
+  if ((rc = sd_xfer_h2d(ctx, din.p, psi_host, bin))) return rc;
   rc = sd_launch_spin_op(ctx, m, dtype, site, op, din.p, dout.p);
   if (rc) return rc;
-  SD_HIP(ctx, hipMemcpyAsync(out_host, dout.p, bout, hipMemcpyDeviceToHost, ctx->stream));
-  SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  return SD_OK;
+  return sd_xfer_d2h(ctx, out_host, dout.p, bout);
 }
 
 int sd_initial_state_index(const sd_model *m, int kind, const int *flips, int nflips, int64_t *idx0_out) {

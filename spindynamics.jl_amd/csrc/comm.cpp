@@ -98,14 +98,23 @@ int sd_comm_exchange_start(sd_ctx *ctx, sd_comm *c, const sd_model *m, int dtype
   // everything queued so far on the compute stream (the pack kernel, the previous apply's readers of the halo) first
   SD_HIP(ctx, hipEventRecord(c->ev_ready, ctx->stream));
   SD_HIP(ctx, hipStreamWaitEvent(c->xstream, c->ev_ready, 0));
+  // an error inside the group must not leave the thread's group open (later RCCL calls would be deferred for ever): note the
+  // first failure, close the group regardless, then report
   SD_NCCL(ctx, c, c->api->GroupStart());
-  for (const sd_slab &s : m->recv_slabs)            // recv offsets are counted from the start of [owned | halo]
-    SD_NCCL(ctx, c, c->api->Recv((double *)halo + (size_t)(s.local_offset - m->n_local) * per, (size_t)s.count * per, NCCL_DOUBLE,
-                                 s.peer, c->nccl, c->xstream));
-  for (const sd_slab &s : m->send_slabs)
-    SD_NCCL(ctx, c, c->api->Send((const double *)src + (size_t)s.local_offset * per, (size_t)s.count * per, NCCL_DOUBLE, s.peer,
-                                 c->nccl, c->xstream));
-  SD_NCCL(ctx, c, c->api->GroupEnd());
+  int bad = 0;
+  for (const sd_slab &s : m->recv_slabs) {          // recv offsets are counted from the start of [owned | halo]
+    if (bad) break;
+    bad = c->api->Recv((double *)halo + (size_t)(s.local_offset - m->n_local) * per, (size_t)s.count * per, NCCL_DOUBLE, s.peer,
+                       c->nccl, c->xstream);
+  }
+  for (const sd_slab &s : m->send_slabs) {
+    if (bad) break;
+    bad = c->api->Send((const double *)src + (size_t)s.local_offset * per, (size_t)s.count * per, NCCL_DOUBLE, s.peer, c->nccl,
+                       c->xstream);
+  }
+  const int end = c->api->GroupEnd();
+  if (bad) return sd_set_err(ctx, SD_ECOMM, std::string("ncclSend/ncclRecv of the halo exchange: ") + c->api->GetErrorString(bad));
+  if (end) return sd_set_err(ctx, SD_ECOMM, std::string("ncclGroupEnd: ") + c->api->GetErrorString(end));
   SD_HIP(ctx, hipEventRecord(c->ev_done, c->xstream));
   return SD_OK;
 }
@@ -189,9 +198,10 @@ int sd_comm_rccl_create(sd_ctx *ctx, int rank, int nranks, const void *id128, sd
   return SD_OK;
 }
 
-// Diagnostic: exercises every RCCL entry point the communicator uses on this rank alone -- ncclAllReduce of two device
-// doubles (sum over nranks copies of (1, 2) when all ranks call it) and a grouped ncclSend/ncclRecv of 1024 doubles to
-// itself -- and checks the bytes.  With one rank it needs no peer: the signature / enum check that a one-GPU box can do.
+// Diagnostic: exercises every RCCL entry point the communicator uses -- ncclAllReduce of two device doubles (sum over nranks
+// copies of (1, 2)) and a grouped ncclSend/ncclRecv of 1024 doubles round the ring of ranks (to itself with one rank) on the
+// communication stream, fenced by the two events as in the halo exchange -- and checks the bytes.  With one rank it needs
+// no peer: the signature / enum check that a one-GPU box can do; bench.py runs it on every rank before the C RCCL leg.
 int sd_comm_selftest(sd_ctx *ctx, sd_comm *c) {
   if (!ctx || !c) return SD_EARG;
   if (c->kind != 1) return sd_set_err(ctx, SD_EARG, "self-test is for the RCCL communicator");
@@ -200,7 +210,7 @@ int sd_comm_selftest(sd_ctx *ctx, sd_comm *c) {
   double *d = nullptr;
   SD_HIP(ctx, hipMalloc((void **)&d, sizeof(double) * (2 * n + 2)));
   std::vector<double> h(2 * n + 2, 0.0);
-  for (int i = 0; i < n; ++i) h[i] = 0.5 * i + 1.0;
+  for (int i = 0; i < n; ++i) h[i] = 0.5 * i + 1.0 + 1000.0 * c->rank;
   h[2 * n] = 1.0; h[2 * n + 1] = 2.0;
   int rc = SD_OK;
   auto body = [&]() -> int {
@@ -208,16 +218,20 @@ int sd_comm_selftest(sd_ctx *ctx, sd_comm *c) {
     SD_NCCL(ctx, c, c->api->AllReduce(d + 2 * n, d + 2 * n, 2, NCCL_DOUBLE, NCCL_SUM, c->nccl, ctx->stream));
     SD_HIP(ctx, hipEventRecord(c->ev_ready, ctx->stream));
     SD_HIP(ctx, hipStreamWaitEvent(c->xstream, c->ev_ready, 0));
+    // with peers: the payload goes round a ring (to rank+1, from rank-1) and carries the sender's rank; alone: to itself
+    const int to = (c->rank + 1) % c->nranks, from = (c->rank + c->nranks - 1) % c->nranks;
     SD_NCCL(ctx, c, c->api->GroupStart());
-    SD_NCCL(ctx, c, c->api->Recv(d + n, n, NCCL_DOUBLE, c->rank, c->nccl, c->xstream));
-    SD_NCCL(ctx, c, c->api->Send(d, n, NCCL_DOUBLE, c->rank, c->nccl, c->xstream));
-    SD_NCCL(ctx, c, c->api->GroupEnd());
+    int bad = c->api->Recv(d + n, n, NCCL_DOUBLE, from, c->nccl, c->xstream);
+    if (!bad) bad = c->api->Send(d, n, NCCL_DOUBLE, to, c->nccl, c->xstream);
+    const int end = c->api->GroupEnd();             // closed whatever happened inside
+    if (bad) return sd_set_err(ctx, SD_ECOMM, std::string("self-test ncclSend/ncclRecv: ") + c->api->GetErrorString(bad));
+    if (end) return sd_set_err(ctx, SD_ECOMM, std::string("self-test ncclGroupEnd: ") + c->api->GetErrorString(end));
     SD_HIP(ctx, hipEventRecord(c->ev_done, c->xstream));
     SD_HIP(ctx, hipStreamWaitEvent(ctx->stream, c->ev_done, 0));
     SD_HIP(ctx, hipMemcpyAsync(h.data(), d, sizeof(double) * h.size(), hipMemcpyDeviceToHost, ctx->stream));
     SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (int i = 0; i < n; ++i)
-      if (h[n + i] != 0.5 * i + 1.0) return sd_set_err(ctx, SD_ECOMM, "self send/recv returned wrong data");
+      if (h[n + i] != 0.5 * i + 1.0 + 1000.0 * from) return sd_set_err(ctx, SD_ECOMM, "ring send/recv returned wrong data");
     if (h[2 * n] != 1.0 * c->nranks || h[2 * n + 1] != 2.0 * c->nranks) return sd_set_err(ctx, SD_ECOMM, "all-reduce returned a wrong sum");
     return SD_OK;
   };

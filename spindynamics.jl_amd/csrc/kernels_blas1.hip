@@ -124,6 +124,16 @@ __global__ __launch_bounds__(BS) void k_nrm2sq(const double *__restrict__ x, int
   if (threadIdx.x == 0) { partials[2 * blockIdx.x] = a; partials[2 * blockIdx.x + 1] = b; }
 }
 
+// number of ComplexF64 elements with a non-zero imaginary part (as a double; exact below 2^53) -> partials
+__global__ __launch_bounds__(BS) void k_imag_count(const double2 *__restrict__ x, int64_t n, double *__restrict__ partials) {
+  __shared__ double red[32];
+  double a = 0.0, b = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) a += (x[i].y != 0.0) ? 1.0 : 0.0;
+  block_reduce2(a, b, red);
+  if (threadIdx.x == 0) { partials[2 * blockIdx.x] = a; partials[2 * blockIdx.x + 1] = b; }
+}
+
 __global__ __launch_bounds__(1024) void k_reduce_to(const double *__restrict__ partials, int n, double *__restrict__ dst) {
   __shared__ double red[32];
   double a = 0.0, b = 0.0;
@@ -367,6 +377,15 @@ int sd_k_nrm2sq(sd_ctx *ctx, const double *x, int64_t n, int slot) {
   int rc = sd_ensure_partials(ctx, 2 * RED_BLOCKS); if (rc) return rc;
   int nb = (int)std::min<int64_t>(RED_BLOCKS, std::max<int64_t>(1, (n + BS - 1) / BS));
   hipLaunchKernelGGL(k_nrm2sq, dim3(nb), dim3(BS), 0, ctx->stream, x, n, ctx->d_partials);
+  hipLaunchKernelGGL(k_reduce_to, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_partials, nb, ctx->d_scalars + slot);
+  SD_HIP(ctx, hipGetLastError());
+  return SD_OK;
+}
+
+int sd_k_imag_count(sd_ctx *ctx, const double *xc, int64_t N, int slot) {
+  int rc = sd_ensure_partials(ctx, 2 * RED_BLOCKS); if (rc) return rc;
+  int nb = (int)std::min<int64_t>(RED_BLOCKS, std::max<int64_t>(1, (N + BS - 1) / BS));
+  hipLaunchKernelGGL(k_imag_count, dim3(nb), dim3(BS), 0, ctx->stream, (const double2 *)xc, N, ctx->d_partials);
   hipLaunchKernelGGL(k_reduce_to, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_partials, nb, ctx->d_scalars + slot);
   SD_HIP(ctx, hipGetLastError());
   return SD_OK;

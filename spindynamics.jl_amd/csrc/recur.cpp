@@ -45,25 +45,18 @@ struct DBuf {   // device work vector, taken from / returned to the context's po
   }
 };
 
-int h2d(sd_ctx *ctx, double *d, const void *h, int64_t doubles) {
-  SD_HIP(ctx, hipMemcpyAsync(d, h, sizeof(double) * (size_t)doubles, hipMemcpyHostToDevice, ctx->stream));
-  SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  return SD_OK;
-}
-int d2h(sd_ctx *ctx, void *h, const double *d, int64_t doubles) {
-  SD_HIP(ctx, hipMemcpyAsync(h, d, sizeof(double) * (size_t)doubles, hipMemcpyDeviceToHost, ctx->stream));
-  SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  return SD_OK;
-}
+// the caller's host vectors (src/PublicAPI.jl:50-88): staged through the context's pinned ring when large (xfer.cpp)
+int h2d(sd_ctx *ctx, double *d, const void *h, int64_t doubles) { return sd_xfer_h2d(ctx, d, h, sizeof(double) * (size_t)doubles); }
+int d2h(sd_ctx *ctx, void *h, const double *d, int64_t doubles) { return sd_xfer_d2h(ctx, h, d, sizeof(double) * (size_t)doubles); }
 int d2d(sd_ctx *ctx, double *dst, const double *src, int64_t doubles) {
   SD_HIP(ctx, hipMemcpyAsync(dst, src, sizeof(double) * (size_t)doubles, hipMemcpyDeviceToDevice, ctx->stream));
   return SD_OK;
 }
 
-// The caller's operator (sd_model_set_apply_callback; the reference's `applyH!` argument): out <- H psi by the callback on the
+// The caller's operator (sd_ctx_set_apply_callback; the reference's `applyH!` argument): out <- H psi by the callback on the
 // context's stream, then the recursion's fused step as one elementwise pass over out.
 int user_op(sd_ctx *ctx, const sd_model *m, int dtype, double *out, const double *psi, int64_t n, int epi, const sd_epi_args &ea) {
-  if (m->user_apply(m->user_apply_data, dtype, out, psi, n, (void *)ctx->stream))
+  if (ctx->user_apply(ctx->user_apply_data, dtype, out, psi, n, (void *)ctx->stream))
     return sd_set_err(ctx, SD_ECOMM, "the apply callback returned an error");
   if (epi == SD_EPI_PLAIN && !ea.negate) return SD_OK;
   return sd_launch_epilogue_only(ctx, dtype, n, out, out, psi, epi, ea);
@@ -71,7 +64,8 @@ int user_op(sd_ctx *ctx, const sd_model *m, int dtype, double *out, const double
 // out <- H psi for the entry points that run their own loop on an unsharded model
 int plain_op(sd_ctx *ctx, const sd_model *m, int dtype, double *out, const double *psi) {
   sd_epi_args ea;
-  if (m->user_apply) return user_op(ctx, m, dtype, out, psi, m->n_local, SD_EPI_PLAIN, ea);
+  ++ctx->n_applies;
+  if (ctx->user_apply) return user_op(ctx, m, dtype, out, psi, m->n_local, SD_EPI_PLAIN, ea);
   return sd_launch_apply(ctx, m, dtype, out, psi, SD_EPI_PLAIN, ea);
 }
 
@@ -85,6 +79,8 @@ struct Op {
   int64_t n = 0;             // rows of this rank (== N unsharded)
   DBuf halo, send;           // imported partner tiles / tiles packed for the peers (sharded plans; ComplexF64-sized)
   bool overlap = true;       // interior tiles run while the exchange is in flight
+  bool use_callback = true;  // false: always the built-in operator (the operator-level entry sd_apply_sharded, which a caller's
+                             // operator may itself call on a sharded model: include/spindyn.h, sd_ctx_set_apply_callback)
 
   int init(sd_ctx *c, const sd_model *mm, sd_comm *cm) {
     if (!c) return SD_EARG;
@@ -102,7 +98,8 @@ struct Op {
   }
   // out = epilogue(H psi) on the owned rows.  Sharded: pack (cell mode), post the exchange, interior tiles, wait, boundary tiles.
   int apply(int dtype, double *out, const double *psi, int epi, sd_epi_args ea) {
-    if (m->user_apply) return user_op(ctx, m, dtype, out, psi, n, epi, ea);
+    ++ctx->n_applies;
+    if (use_callback && ctx->user_apply) return user_op(ctx, m, dtype, out, psi, n, epi, ea);
     if (m->nranks == 1) return sd_launch_apply(ctx, m, dtype, out, psi, epi, ea, 0);
     ea.halo = halo.p;
     const void *src = psi;
@@ -538,6 +535,7 @@ extern "C" int sd_apply_sharded(sd_ctx *ctx, const sd_model *m, sd_comm *comm, i
   Op op; RC(op.init(ctx, m, comm));
   if (n_local != op.n) return sd_set_err(ctx, SD_EDIM, "vector length does not match the local basis dimension");
   op.overlap = overlap != 0;
+  op.use_callback = false;      // operator level: always the built-in H
   sd_epi_args ea;
   RC(op.apply(dtype, (double *)out_dev, (const double *)psi_dev, SD_EPI_PLAIN, ea));
   SD_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the halo / send buffers go back to the pool
@@ -855,8 +853,36 @@ static int kpm_sqw_core(Op &op, int dtype, const void *psi0, bool on_dev, int64_
   std::vector<double> mu(kpm_m), g(kpm_m);
   sd_kpm_kernel(kpm_m, kernel, g.data());
   int rc = 0;
+  // H is real in the S^z basis, so for a real psi0 phi_{2pi-q} = conj(phi_q) and mu_n(2pi - q) = mu_n(q): every pair
+  // (q, 2pi - q) of the list -- momenta(model) always holds both -- is computed once and its row copied (DESIGN 6.10;
+  // the reference recomputes it, src/KPM_Sqw.jl:218-252, and differs from the copy by the rounding of exp(iqr) only).
+  // Not with a caller's operator (it need not be real); sd_ctx_set_kpm_pair_q(ctx, 0) switches it off.
+  std::vector<int> same_as((size_t)std::max(Qn, 0), -1);
+  if (ctx->kpm_pair_q && !ctx->user_apply && Qn > 1) {
+    bool real_psi = dtype == SD_F64;
+    if (!real_psi) {
+      RC(sd_k_imag_count(ctx, psic.p, n, 6));
+      RC(op.reduce(ctx->d_scalars + 6, 1));
+      double cnt[1]; RC(sd_read_scalars(ctx, 6, 1, cnt));
+      real_psi = cnt[0] == 0.0;
+    }
+    if (real_psi) {
+      const double two_pi = 6.283185307179586476925286766559;
+      for (int j = 1; j < Qn; ++j)
+        for (int i = 0; i < j; ++i) {
+          if (same_as[i] >= 0) continue;
+          const double sum = q[i] + q[j], k = std::nearbyint(sum / two_pi);
+          const double tol = 8 * 2.220446049250313e-16 * std::max(two_pi, std::max(std::fabs(q[i]), std::fabs(q[j])));
+          if (std::fabs(sum - k * two_pi) <= tol) { same_as[j] = i; break; }
+        }
+    }
+  }
   for (int iq = 0; iq < Qn; ++iq) {                                                       // :218 (serial over q)
     double *Srow = Smat + (size_t)iq * W;
+    if (same_as[iq] >= 0) {
+      std::memcpy(Srow, Smat + (size_t)same_as[iq] * W, sizeof(double) * (size_t)W);
+      continue;
+    }
     RC(sd_launch_szq(ctx, m, SD_C128, psic.p, q[iq], phi.p));                             // :223
     const double norm_phi = norm_dev(op, phi.p, 2 * n, &rc); RC(rc);
     if (norm_phi == 0) { for (int iw = 0; iw < W; ++iw) Srow[iw] = 0.0; continue; }       // :226-229

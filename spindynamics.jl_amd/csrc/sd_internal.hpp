@@ -42,6 +42,8 @@ struct sd_tile_rec {
   int32_t pad0, pad1;
 };
 
+struct sd_xfer_team;   // host threads of the staged host <-> device transfers (xfer.cpp)
+
 struct sd_ctx {
   int device = 0;
   hipStream_t own_stream = nullptr;
@@ -59,6 +61,15 @@ struct sd_ctx {
   void *stage[2] = {nullptr, nullptr};   // device staging of the host-pointer operator calls (sd_apply, ...), kept between calls
   size_t stage_cap[2] = {0, 0};
   int kpm_doubling = 1;     // sd_ctx_set_kpm_doubling: two Chebyshev moments per apply (default) or the reference's one
+  // pinned ring + copy team of the large host <-> device transfers (xfer.cpp), created on first use
+  void *xfer_buf[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t xfer_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  size_t xfer_chunk = 0;
+  sd_xfer_team *xfer_team = nullptr;
+  sd_apply_fn user_apply = nullptr;   // recursion-level operator supplied by the caller (sd_ctx_set_apply_callback), or null
+  void *user_apply_data = nullptr;
+  int64_t n_applies = 0;    // operator applications the recursion-level entries have queued on this context (sd_ctx_apply_count)
+  int kpm_pair_q = 1;       // sd_ctx_set_kpm_pair_q: for a real psi0 compute S(q,w) once per pair (q, 2pi - q) and copy the row
 };
 
 // Device-side view of a model, passed by value to kernels.
@@ -127,8 +138,6 @@ struct sd_model {
   int64_t fs_halo_off[SD_FS_MAX_RANKS] = {-1, -1, -1, -1, -1, -1, -1, -1};
   int64_t fs_peer_lo[SD_FS_MAX_RANKS] = {0};
   int rank = 0, nranks = 1;
-  sd_apply_fn user_apply = nullptr;   // recursion-level operator supplied by the caller (sd_model_set_apply_callback), or null
-  void *user_apply_data = nullptr;
   int64_t row_lo = 0, row_hi = 0, n_local = 0, n_halo = 0;
   std::vector<uint32_t> tile_prefix;  // local tiles
   std::vector<int64_t> tile_base;
@@ -207,6 +216,7 @@ int sd_launch_szq(sd_ctx *ctx, const sd_model *m, int dtype_in, const void *psi0
 int sd_k_dot(sd_ctx *ctx, int nc, const double *x, const double *y, int64_t N, int slot);  // conj(x).y -> [slot]=re,[slot+1]=im
 int sd_k_dotu(sd_ctx *ctx, const double *x, const double *y, int64_t N, int slot);          // complex sum x_i*y_i, NO conjugation -> [slot]=re,[slot+1]=im
 int sd_k_nrm2sq(sd_ctx *ctx, const double *x, int64_t n, int slot);
+int sd_k_imag_count(sd_ctx *ctx, const double *xc, int64_t N, int slot);   // ComplexF64 elements with Im != 0 -> d_scalars[slot] (d_scalars[slot+1] = 0)
 // three-term update on un-normalised Lanczos vectors (kernels_blas1.hip, k_lanczos_fold): t <- w, |w|^2 -> n2_out[0..1]
 int sd_k_lanczos_fold(sd_ctx *ctx, double *t, const double *uc, const double *up, int64_t N, int form, const double *dot_dev,
                       const double *n2c_dev, const double *n2p_dev, double *store_alpha, double *store_bc, double *n2_out);
@@ -244,6 +254,12 @@ int sd_comm_nranks(const sd_comm *c);
 int sd_comm_exchange_start(sd_ctx *ctx, sd_comm *c, const sd_model *m, int dtype, const void *src, void *halo);
 int sd_comm_exchange_wait(sd_ctx *ctx, sd_comm *c, const sd_model *m);
 int sd_comm_allreduce_dev(sd_ctx *ctx, sd_comm *c, double *vals_dev, int count);   // in place, ordered on ctx->stream
+
+// host <-> device copies of the host-pointer entry points, complete on return (xfer.cpp: pinned ring + host thread team for
+// large transfers); ordered after the work already queued on ctx->stream
+int sd_xfer_h2d(sd_ctx *ctx, void *dev, const void *host, size_t bytes);
+int sd_xfer_d2h(sd_ctx *ctx, void *host, const void *dev, size_t bytes);
+void sd_xfer_release(sd_ctx *ctx);
 
 // grows ctx->d_partials to at least `doubles` entries (scratch for per-workgroup partial sums)
 int sd_ensure_partials(sd_ctx *ctx, size_t doubles);

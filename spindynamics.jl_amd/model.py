@@ -60,13 +60,13 @@ class Model:
         return self.N
 
     def set_apply(self, fn):
-        """Install `fn(out, psi, model)` as the operator of every recursion on this model (the reference's applyH! argument;
-        sd_model_set_apply_callback), or restore the built-in operator with fn=None.  out and psi are torch tensors on the
+        """Install `fn(out, psi, model)` as the operator of every recursion run on this model's context (the reference's
+        applyH! argument; sd_ctx_set_apply_callback), or restore the built-in operator with fn=None.  out and psi are torch tensors on the
         model's device (Float64 or ComplexF64, this rank's rows), valid during the call only; fn runs with torch's current
         stream set to the library's stream and must write H psi into out."""
         self._apply_err = None
         if fn is None:
-            check(lib().sd_model_set_apply_callback(self.h, _lib.APPLY_FN(), None))
+            check(lib().sd_ctx_set_apply_callback(self.ctx.h, _lib.APPLY_FN(), None))
             self._apply_cb = None
             return
 
@@ -88,7 +88,7 @@ class Model:
                 return 1
 
         self._apply_cb = _lib.APPLY_FN(tramp)       # keeps the trampoline alive
-        check(lib().sd_model_set_apply_callback(self.h, self._apply_cb, None))
+        check(lib().sd_ctx_set_apply_callback(self.ctx.h, self._apply_cb, None))
 
     # -- basis queries (host) --
     def states_range(self, start, count):

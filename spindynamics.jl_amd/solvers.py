@@ -3,7 +3,7 @@ the device through one C-ABI call (include/spindyn.h, "recursion level").
 
 The `applyH` argument of the reference functions is honoured: hamiltonian.apply_H selects the built-in fused
 operator; any other callable `applyH(out, psi, model)` on torch device tensors is installed as the operator of the
-recursion for the duration of the call (sd_model_set_apply_callback: the library calls it for out <- H psi and
+recursion for the duration of the call (sd_ctx_set_apply_callback: the library calls it for out <- H psi and
 applies its fused step as a second pass).
 Where the reference draws a start vector from Julia's RNG (which cannot be
 reproduced outside Julia) a `psi0=` / `seed=` keyword is offered instead of

@@ -93,9 +93,9 @@ int main(int argc, char **argv) {
     struct fwd f;
     double *mu_cb = (double *)malloc(sizeof(double) * (size_t)M);
     f.ctx = ctx; f.model = model; f.calls = 0;
-    CHECK(sd_model_set_apply_callback(model, forward_apply, &f));
+    CHECK(sd_ctx_set_apply_callback(ctx, forward_apply, &f));
     CHECK(sd_kpm_moments(ctx, model, phi, N, (int)M, par[6], par[7], mu_cb));
-    CHECK(sd_model_set_apply_callback(model, NULL, NULL));
+    CHECK(sd_ctx_set_apply_callback(ctx, NULL, NULL));
     if (f.calls < 1 || maxdiff(mu_cb, mu_got, M) > 1e-13) {
       fprintf(stderr, "apply callback: %d calls, moments differ by %g\n", f.calls, maxdiff(mu_cb, mu_got, M));
       return 1;

@@ -347,26 +347,30 @@ def test_lanczos_tridiag_breakdown_is_applied_after_the_queued_recursion(pkg, O,
 
 
 def test_long_queued_lanczos_stops_soon_after_a_breakdown(pkg):
-    """A breakdown at step 1 with lanc_m = 12000 (capped at N = 12870): the queued recursion looks at the betas every 32 steps and stops; the result
-    is the reference's (alpha = [E], m_eff = 1) and the call does not run 500 garbage steps (wall time bound)."""
-    import time
+    """A breakdown at step 1 with lanc_m = 12000 (capped at N = 12870): the queued recursion looks at the betas every 32 steps
+    (SD_BREAK_PEEK, csrc/recur.cpp) and stops; the result is the reference's (alpha = [E], m_eff = 1) and the call queues at
+    most two peek intervals of garbage steps, counted by the library itself (sd_ctx_apply_count) -- no wall-clock bound."""
     L, nup = 16, 8
     m = pkg.XXZChain(L, nup=nup)
     v = np.ones(m.N, dtype=complex)
+    n0 = m.ctx.apply_count()
     pkg.lanczos_tridiag(pkg.apply_H, m, v, lanc_m=4)
-    t0 = time.time()
+    assert m.ctx.apply_count() - n0 == 4              # the counter counts recursion steps
+    n0 = m.ctx.apply_count()
     al, be, _ = pkg.lanczos_tridiag(pkg.apply_H, m, v, lanc_m=12000)
-    dt = time.time() - t0
+    steps = m.ctx.apply_count() - n0
     assert len(al) == 1 and abs(al[0] - (L - 1) / 4) < 1e-13
-    assert dt < 0.12                                  # 12000 queued steps would take ~0.25 s even at 20 us each; 32 take ~1 ms
+    assert 1 <= steps <= 64, steps                    # not 12000: stopped at the first or second look at the betas
+    n0 = m.ctx.apply_count()
     lo, hi = pkg.lanczos_extremal(pkg.apply_H, m, lanc_m=300, psi0=v)
     assert abs(lo - (L - 1) / 4) < 1e-13 and abs(hi - (L - 1) / 4) < 1e-13
+    assert 1 <= m.ctx.apply_count() - n0 <= 64
 
 
 def test_user_operator_at_recursion_level(pkg, O):
     """The reference's solvers take the operator as a callable (src/Lanczos.jl:27-29, src/TimeEvolution/Chebyshev.jl:61-64,
     src/KPM_Sqw.jl:95-98).  A user callable applyH(out, psi, model) on device tensors replaces the built-in kernel inside every
-    recursion (sd_model_set_apply_callback): here 2*H written as a closure over the library's own apply, against the built-in
+    recursion (sd_ctx_set_apply_callback): here 2*H written as a closure over the library's own apply, against the built-in
     operator of the model with doubled couplings (a power-of-two scale: every intermediate doubles exactly)."""
     L, nup = 12, 6
     m = pkg.XXZChain(L, nup=nup, Jz=0.7, hz=0.1)
@@ -417,3 +421,43 @@ def test_user_operator_at_recursion_level(pkg, O):
     assert len(calls) == n_before and abs(2 * lo3 - lo) < 1e-10
     with pytest.raises(pkg.ArgumentError):
         pkg.lanczos_extremal("not callable", m)
+
+
+def test_kpm_sqw_pairs_q_with_2pi_minus_q_for_a_real_psi0(pkg, O):
+    """H is real, so for a real psi0 phi_{2pi-q} = conj(phi_q) and the moments of q and 2pi - q agree: sd_kpm_sqw computes
+    each pair of momenta(model) once and copies the row (the reference recomputes it, src/KPM_Sqw.jl:218-252).
+    Pairing on == pairing off to 1e-12 (rounding of exp(iqr)), both within the 1e-8 bar of the oracle; a complex psi0, or a
+    Float64 one passed as ComplexF64 with a non-zero imaginary part somewhere, is never paired."""
+    L, nup = 12, 6
+    m = pkg.XXZChain(L, Jz=0.9, nup=nup)
+    r = O.XXZChain(L, Jz=0.9, nup=nup)
+    rng = np.random.default_rng(3)
+    psi = rng.standard_normal(m.N)
+    psi /= np.linalg.norm(psi)
+    q, omega = pkg.momenta(m), np.arange(-1.0, 4.0, 0.1)
+    a, b = O.rescaling_from_bounds(-L / 2, L / 2)
+    want = O.kpm_sqw(r, psi, q, omega, a, b, kpm_m=96)
+    try:
+        for vec in (psi, psi.astype(np.complex128)):
+            m.ctx.set_kpm_pair_q(True)
+            S_on = pkg.kpm_sqw(vec, m, q, omega, a=a, b=b, kpm_m=96)
+            m.ctx.set_kpm_pair_q(False)
+            S_off = pkg.kpm_sqw(vec, m, q, omega, a=a, b=b, kpm_m=96)
+            for n in range(1, L):
+                assert np.array_equal(S_on[n], S_on[L - n])                    # the row was copied
+            assert np.abs(S_on - S_off).max() <= 1e-12 * max(1.0, np.abs(S_off).max())
+            assert np.abs(S_on - want).max() <= 1e-8 * max(1.0, np.abs(want).max())
+            assert np.abs(S_off - want).max() <= 1e-8 * max(1.0, np.abs(want).max())
+        # complex psi0: S(q) != S(2pi - q) in general, nothing may be copied
+        m.ctx.set_kpm_pair_q(True)
+        psic = psi + 1j * rng.standard_normal(m.N) * 0.3
+        psic /= np.linalg.norm(psic)
+        Sc = pkg.kpm_sqw(psic, m, q, omega, a=a, b=b, kpm_m=96)
+        wantc = O.kpm_sqw(r, psic, q, omega, a, b, kpm_m=96)
+        assert np.abs(Sc - wantc).max() <= 1e-8 * max(1.0, np.abs(wantc).max())
+        assert not np.array_equal(Sc[1], Sc[L - 1])
+        # a list that holds q but not 2pi - q is computed as it stands
+        S3 = pkg.kpm_sqw(psi, m, q[:3], omega, a=a, b=b, kpm_m=96)
+        assert np.abs(S3 - want[:3]).max() <= 1e-8 * max(1.0, np.abs(want).max())
+    finally:
+        m.ctx.set_kpm_pair_q(True)
