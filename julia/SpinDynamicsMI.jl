@@ -125,7 +125,17 @@ function apply_H!(out::Vector{T}, ψ::Vector{T}, model::Model) where {T<:Union{F
 end
 
 function apply_rescaled_H!(out::Vector{T}, ψ::Vector{T}, applyH!, model::Model, a::Float64, b::Float64) where {T<:Union{Float64,ComplexF64}}
-    applyH! === apply_H! || throw(ArgumentError("apply_rescaled_H! is fused with the device apply: pass apply_H!"))
+    length(out) == length(ψ) || throw(DimensionMismatch("length(out) != length(ψ)"))
+    if applyH! !== apply_H!
+        # any other callable, as the reference takes it (src/Hamiltonian.jl:285-301): H ψ by the caller's operator, then the
+        # rescaling pass on the host with the reference's own arithmetic
+        applyH!(out, ψ, model)
+        @inbounds for i in eachindex(out)
+            out[i] = (out[i] - b * ψ[i]) / a
+        end
+        return out
+    end
+    # the built-in operator: apply and rescaling fused in one device pass (same arithmetic per element)
     check(ccall((:sd_apply_rescaled, libspindyn), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Float64, Float64),
                 model.ctx.h, model.h, dtype_code(T), out, ψ, length(ψ), a, b), model.ctx.h)
     return out

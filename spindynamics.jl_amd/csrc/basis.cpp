@@ -154,27 +154,40 @@ static void xcd_order(const sd_model *m, int p, std::vector<uint32_t> &tp_io, st
     int B0 = 1;     // first bond considered as an orbit generator (two-pass probe: the bonds below belong to the other pass)
     if (const char *e = getenv("SD_XCD_ORBIT_FROM")) B0 = std::max(1, atoi(e));
     const size_t nt = tp_io.size();
-    auto first_seen_reset = [&](uint32_t P) {
-      uint32_t C0 = P; int ng = 0;
-      for (int b = B0; b + 1 <= p && ng < FO; b += 2)
+    // A wrap bond (1, j) with j in the suffix -- the periodic chain's (L, 1) -- maps tile P onto the ONE tile P ^ 1 (site 1
+    // flipped): with it, site 1 alone becomes a generator (P and P ^ 1 are queued next to each other, so the gather of the wrap
+    // bond finds the partner's rows in this XCD's L2) and the pair generators start at bond 2.  SD_XCD_WRAP=0 disables.
+    bool wrap = false;
+    {
+      const char *e = getenv("SD_XCD_WRAP");
+      if (!(e && atoi(e) == 0) && B0 == 1) {
+        const int nn = count_nn_hops(m);
+        for (size_t h = (size_t)nn; h < m->hop_i.size() && !wrap; ++h) {
+          const int i = m->hop_i[h], j = m->hop_j[h];
+          wrap = (i == 1 && j > p) || (j == 1 && i > p);
+        }
+      }
+    }
+    const int Bp = wrap ? 2 : B0, FOp = wrap ? std::max(FO - 1, 0) : FO;
+    // canonical orbit representative: chosen pairs set to (up, down) (site 1 down with a wrap bond); member id = what is flipped
+    auto canon = [&](uint32_t P, int *member_out) {
+      uint32_t C0 = P; int member = 0, ng = 0, sh = 0;
+      if (wrap) { member = (int)(P & 1u); C0 &= ~1u; sh = 1; }
+      for (int b = Bp; b + 1 <= p && ng < FOp; b += 2)
         if (((P >> (b - 1)) ^ (P >> b)) & 1u) {
-          if (!((P >> (b - 1)) & 1u)) C0 ^= 3u << (b - 1);
+          if (!((P >> (b - 1)) & 1u)) { C0 ^= 3u << (b - 1); member |= 1 << (ng + sh); }
           ++ng;
         }
-      first_seen[C0] = -1;
+      if (member_out) *member_out = member;
+      return C0;
     };
+    auto first_seen_reset = [&](uint32_t P) { first_seen[canon(P, nullptr)] = -1; };
     if (FO > 0 && nt >= 64 && p >= 3 && count_nn_hops(m) > 0) {
-      // canonical orbit representative: chosen pairs set to (up, down); member id = which pairs are flipped
       std::vector<uint64_t> key(nt);     // (first-seen rank of the orbit) << 8 | member id
       int64_t n_orb = 0;
       for (size_t k = 0; k < nt; ++k) {
-        const uint32_t P = tp_io[k];
-        uint32_t C0 = P; int member = 0, ng = 0;
-        for (int b = B0; b + 1 <= p && ng < FO; b += 2)
-          if (((P >> (b - 1)) ^ (P >> b)) & 1u) {
-            if (!((P >> (b - 1)) & 1u)) { C0 ^= 3u << (b - 1); member |= 1 << ng; }
-            ++ng;
-          }
+        int member = 0;
+        const uint32_t C0 = canon(tp_io[k], &member);
         if (first_seen[C0] < 0) first_seen[C0] = n_orb++;
         key[k] = ((uint64_t)first_seen[C0] << 8) | (uint64_t)member;
       }

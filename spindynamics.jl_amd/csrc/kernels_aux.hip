@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 #include "device_common.hpp"
 
@@ -51,6 +52,39 @@ __global__ __launch_bounds__(256) void k_szq_tiled(sd_dev_model dm, SzqPhases ph
     double sr = pr, si = pi;
     szq_sum(ph, (uint64_t)sufS[i] << dm.p, dm.p, dm.L, sr, si);
     szq_store<NCIN>(sr, si, normfact, psi0, base + i, phi);
+  }
+}
+
+// Full 2^L basis (idx = state), L >= 12.  Site r+1 is bit r of the row index, and the site sum runs r = 0..L-1, so rows that
+// share their LOW k index bits share the FIRST k terms of the sum.  A thread keeps one value b of those bits, forms the first
+// k terms once and walks J values of the high bits: per row only the remaining L-k terms are added, and these depend on the
+// (workgroup-uniform) high bits alone, so each is one add of +-(phase/2) -- exactly the product phase * (+-0.5) of the
+// reference (scaling by 0.5 is exact) -- selected on the scalar unit.  Same additions in the same order as the one-row-per-
+// thread loop, 40-50 instead of ~200 lane-operations per row; consecutive lanes hold consecutive rows (16-B accesses).
+template <int NCIN>
+__global__ __launch_bounds__(256) void k_szq_full(sd_dev_model dm, SzqPhases ph, double normfact, int k, int J,
+                                                  const double *__restrict__ psi0, double2 *__restrict__ phi) {
+  const uint32_t nlb = (1u << k) >> 8;                           // workgroups per value of the high bits (2^k / 256)
+  const uint32_t bb = blockIdx.x % nlb;
+  const int64_t jc = blockIdx.x / nlb;
+  const uint32_t b = (bb << 8) + threadIdx.x;
+  double pr = 0.0, pi = 0.0;
+  szq_sum(ph, (uint64_t)b, 0, k, pr, pi);
+  const int64_t n_high = dm.n_local >> k;
+  const uint64_t hi0 = (uint64_t)(dm.row_lo >> k);               // sharded by the top index bits: this rank's high bits start here
+  const int L = dm.L;
+  int64_t j1 = (jc + 1) * J;
+  if (j1 > n_high) j1 = n_high;
+  for (int64_t j = jc * J; j < j1; ++j) {
+    const uint64_t hs = hi0 + (uint64_t)j;
+    double sr = pr, si = pi;
+    for (int r = k; r < L; ++r) {
+      const bool up = (hs >> (r - k)) & 1;
+      const double hr = 0.5 * ph.re[r], hi = 0.5 * ph.im[r];     // exact; == ph * sz_of(bit) in magnitude
+      sr += up ? hr : -hr;
+      si += up ? hi : -hi;
+    }
+    szq_store<NCIN>(sr, si, normfact, psi0, (j << k) + (int64_t)b, phi);
   }
 }
 
@@ -302,6 +336,20 @@ int sd_launch_szq(sd_ctx *ctx, const sd_model *m, int dtype_in, const void *psi0
                          (const double *)psi0, (double2 *)phi);
     else
       hipLaunchKernelGGL(k_szq_tiled<1>, dim3(dm.n_tiles), dim3(256), 0, ctx->stream, dm, ph, normfact,
+                         (const double *)psi0, (double2 *)phi);
+  } else if (m->full_ls > 0 && dm.L >= 12 && (dm.n_local >> 9) > 0 && !getenv("SD_SZQ_FULL_GENERIC")) {
+    // full basis: k low index bits per thread-constant prefix sum (2^k >= 256 rows per workgroup pass), J high-bit values per thread
+    int k = dm.L / 2;
+    if (k < 8) k = 8;
+    while (k > 8 && (dm.n_local >> k) < 16) --k;                 // a sharded rank owns 2^(L-d) rows: keep at least 16 high values if possible
+    const int64_t n_high = dm.n_local >> k;
+    const int J = (int)std::min<int64_t>(16, n_high);
+    const int64_t nb = ((n_high + J - 1) / J) * (int64_t)((1u << k) >> 8);
+    if (dtype_in == SD_C128)
+      hipLaunchKernelGGL(k_szq_full<2>, dim3((unsigned)nb), dim3(256), 0, ctx->stream, dm, ph, normfact, k, J,
+                         (const double *)psi0, (double2 *)phi);
+    else
+      hipLaunchKernelGGL(k_szq_full<1>, dim3((unsigned)nb), dim3(256), 0, ctx->stream, dm, ph, normfact, k, J,
                          (const double *)psi0, (double2 *)phi);
   } else {
     int64_t nb = (dm.n_local + 255) / 256;

@@ -89,7 +89,8 @@ def test_long_range_and_general_bonds(pkg, O):
 
 def test_szq_vs_oracle(pkg, O):
     # tolerance: phases come from the host libm on both sides; the device multiplies in the same order -> 1e-15 abs
-    for (L, nup) in [(6, 3), (12, 6), (16, 8), (9, None)]:
+    # full basis with L >= 12: k_szq_full (first k terms of the site sum once per thread, one add per remaining term)
+    for (L, nup) in [(6, 3), (12, 6), (16, 8), (9, None), (12, None), (15, None), (17, None)]:
         m = pkg.XXZChain(L, nup=nup)
         r = O.XXZChain(L, nup=nup)
         for cplx in (True, False):
@@ -98,6 +99,34 @@ def test_szq_vs_oracle(pkg, O):
                 got = pkg.Sz_q_vector(m, psi, q)
                 want = O.Sz_q_vector(r, psi, q)
                 assert np.abs(got - want).max() <= 1e-15 * max(1.0, np.abs(want).max())
+
+
+def test_szq_full_basis_kernel_equals_the_row_loop_bit_for_bit(pkg, monkeypatch):
+    """k_szq_full shares the first k terms of the site sum among the rows with equal low index bits and adds +-(phase/2) where
+    the row loop multiplies phase * (+-0.5): the same additions in the same order, so the same bits as k_szq_generic
+    (SD_SZQ_FULL_GENERIC=1), for real and complex input, also when the vector is one rank's share of a sharded full basis."""
+    import torch
+    for L in (12, 14, 19):
+        m = pkg.XXZChain(L)
+        for cplx in (True, False):
+            psi = rand_vec(m.N, 40 + L, cplx)
+            for q in (0.3, 2 * np.pi * 5 / L):
+                monkeypatch.delenv("SD_SZQ_FULL_GENERIC", raising=False)
+                a = pkg.Sz_q_vector(m, psi, q)
+                monkeypatch.setenv("SD_SZQ_FULL_GENERIC", "1")
+                b = pkg.Sz_q_vector(m, psi, q)
+                assert np.array_equal(a, b)
+    monkeypatch.delenv("SD_SZQ_FULL_GENERIC", raising=False)
+    L, P = 14, 4
+    full = pkg.XXZChain(L)
+    psi = rand_vec(full.N, 9, True)
+    want = pkg.Sz_q_vector(full, psi, 1.1)
+    for r in range(P):
+        m = pkg.XXZChain(L)
+        op = pkg.ShardedOperator(m, r, P, mode="range")
+        rows = m.local_rows()
+        got = op.Sz_q_vector(torch.from_numpy(psi[rows].copy()).cuda(), 1.1).cpu().numpy()
+        assert np.array_equal(got, want[rows])
 
 
 def test_dimension_and_argument_errors(pkg):
