@@ -57,35 +57,44 @@ __global__ __launch_bounds__(256) void k_szq_tiled(sd_dev_model dm, SzqPhases ph
 
 // Full 2^L basis (idx = state), L >= 12.  Site r+1 is bit r of the row index, and the site sum runs r = 0..L-1, so rows that
 // share their LOW k index bits share the FIRST k terms of the sum.  A thread keeps one value b of those bits, forms the first
-// k terms once and walks J values of the high bits: per row only the remaining L-k terms are added, and these depend on the
-// (workgroup-uniform) high bits alone, so each is one add of +-(phase/2) -- exactly the product phase * (+-0.5) of the
-// reference (scaling by 0.5 is exact) -- selected on the scalar unit.  Same additions in the same order as the one-row-per-
-// thread loop, 40-50 instead of ~200 lane-operations per row; consecutive lanes hold consecutive rows (16-B accesses).
+// k terms once and carries 16 rows -- 16 consecutive values of the high bits -- in registers: the remaining L-k terms are
+// added site by site, each one add of +-(phase/2) per row (exactly the product phase * (+-0.5) of the reference: scaling by
+// 0.5 is exact), with the sign known at compile time for the four sites that count the 16 rows and uniform for the sites
+// above.  Same additions in the same order as the one-row-per-thread loop, ~45 instead of ~200 lane-operations per row;
+// consecutive lanes hold consecutive rows (16-B accesses), 16 loads and 16 stores in flight per thread.
 template <int NCIN>
-__global__ __launch_bounds__(256) void k_szq_full(sd_dev_model dm, SzqPhases ph, double normfact, int k, int J,
+__global__ __launch_bounds__(256) void k_szq_full(sd_dev_model dm, SzqPhases ph, double normfact, int k,
                                                   const double *__restrict__ psi0, double2 *__restrict__ phi) {
-  const uint32_t nlb = (1u << k) >> 8;                           // workgroups per value of the high bits (2^k / 256)
+  constexpr int J = 16;
+  const uint32_t nlb = (1u << k) >> 8;                           // workgroups per 16 values of the high bits (2^k / 256)
   const uint32_t bb = blockIdx.x % nlb;
-  const int64_t jc = blockIdx.x / nlb;
+  const int64_t j0 = (int64_t)(blockIdx.x / nlb) * J;
   const uint32_t b = (bb << 8) + threadIdx.x;
   double pr = 0.0, pi = 0.0;
   szq_sum(ph, (uint64_t)b, 0, k, pr, pi);
-  const int64_t n_high = dm.n_local >> k;
-  const uint64_t hi0 = (uint64_t)(dm.row_lo >> k);               // sharded by the top index bits: this rank's high bits start here
+  double sr[J], si[J];
+#pragma unroll
+  for (int j = 0; j < J; ++j) { sr[j] = pr; si[j] = pi; }
   const int L = dm.L;
-  int64_t j1 = (jc + 1) * J;
-  if (j1 > n_high) j1 = n_high;
-  for (int64_t j = jc * J; j < j1; ++j) {
-    const uint64_t hs = hi0 + (uint64_t)j;
-    double sr = pr, si = pi;
-    for (int r = k; r < L; ++r) {
-      const bool up = (hs >> (r - k)) & 1;
-      const double hr = 0.5 * ph.re[r], hi = 0.5 * ph.im[r];     // exact; == ph * sz_of(bit) in magnitude
-      sr += up ? hr : -hr;
-      si += up ? hi : -hi;
+  // sharded by the top index bits: this rank's high bits start at row_lo >> k, a multiple of 16 like j0
+  const uint64_t hs0 = (uint64_t)(dm.row_lo >> k) + (uint64_t)j0;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {                                  // sites k+1 .. k+4: bit t of the row counter j
+    const double hr = 0.5 * ph.re[k + t], hi = 0.5 * ph.im[k + t];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      if ((j >> t) & 1) { sr[j] += hr; si[j] += hi; }
+      else { sr[j] += -hr; si[j] += -hi; }
     }
-    szq_store<NCIN>(sr, si, normfact, psi0, (j << k) + (int64_t)b, phi);
   }
+  for (int r = k + 4; r < L; ++r) {                              // sites above: the same for the 16 rows
+    const bool up = (hs0 >> (r - k)) & 1;
+    const double hr = up ? 0.5 * ph.re[r] : -(0.5 * ph.re[r]), hi = up ? 0.5 * ph.im[r] : -(0.5 * ph.im[r]);
+#pragma unroll
+    for (int j = 0; j < J; ++j) { sr[j] += hr; si[j] += hi; }
+  }
+#pragma unroll
+  for (int j = 0; j < J; ++j) szq_store<NCIN>(sr[j], si[j], normfact, psi0, ((j0 + j) << k) + (int64_t)b, phi);
 }
 
 template <int NCIN>
@@ -337,19 +346,19 @@ int sd_launch_szq(sd_ctx *ctx, const sd_model *m, int dtype_in, const void *psi0
     else
       hipLaunchKernelGGL(k_szq_tiled<1>, dim3(dm.n_tiles), dim3(256), 0, ctx->stream, dm, ph, normfact,
                          (const double *)psi0, (double2 *)phi);
-  } else if (m->full_ls > 0 && dm.L >= 12 && (dm.n_local >> 9) > 0 && !getenv("SD_SZQ_FULL_GENERIC")) {
-    // full basis: k low index bits per thread-constant prefix sum (2^k >= 256 rows per workgroup pass), J high-bit values per thread
+  } else if (m->full_ls > 0 && dm.L >= 12 && (dm.n_local >> 12) > 0 && !getenv("SD_SZQ_FULL_GENERIC")) {
+    // full basis: k low index bits per thread-constant prefix sum (2^k >= 256 rows per workgroup pass), 16 values of the high
+    // bits per thread (a rank of a sharded basis owns 2^(L-d) rows: at least 16 x 256 of them, else the row loop below)
     int k = dm.L / 2;
     if (k < 8) k = 8;
-    while (k > 8 && (dm.n_local >> k) < 16) --k;                 // a sharded rank owns 2^(L-d) rows: keep at least 16 high values if possible
-    const int64_t n_high = dm.n_local >> k;
-    const int J = (int)std::min<int64_t>(16, n_high);
-    const int64_t nb = ((n_high + J - 1) / J) * (int64_t)((1u << k) >> 8);
+    while (k > 8 && (dm.n_local >> k) < 16) --k;
+    const int64_t n_high = dm.n_local >> k;                      // a power of two >= 16
+    const int64_t nb = (n_high / 16) * (int64_t)((1u << k) >> 8);
     if (dtype_in == SD_C128)
-      hipLaunchKernelGGL(k_szq_full<2>, dim3((unsigned)nb), dim3(256), 0, ctx->stream, dm, ph, normfact, k, J,
+      hipLaunchKernelGGL(k_szq_full<2>, dim3((unsigned)nb), dim3(256), 0, ctx->stream, dm, ph, normfact, k,
                          (const double *)psi0, (double2 *)phi);
     else
-      hipLaunchKernelGGL(k_szq_full<1>, dim3((unsigned)nb), dim3(256), 0, ctx->stream, dm, ph, normfact, k, J,
+      hipLaunchKernelGGL(k_szq_full<1>, dim3((unsigned)nb), dim3(256), 0, ctx->stream, dm, ph, normfact, k,
                          (const double *)psi0, (double2 *)phi);
   } else {
     int64_t nb = (dm.n_local + 255) / 256;

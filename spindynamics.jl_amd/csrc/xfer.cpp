@@ -182,8 +182,8 @@ int staged_d2h(sd_ctx *ctx, char *host, const char *dev, size_t bytes, size_t ch
 
 int xfer(sd_ctx *ctx, void *dst, const void *src, size_t bytes, hipMemcpyKind kind) {
   if (bytes == 0) return SD_OK;
-  static const Mode mode = mode_from_env();
-  static const size_t min_bytes = env_mb("SD_XFER_MIN_MB", 16), chunk = env_mb("SD_XFER_CHUNK_MB", 32);
+  const Mode mode = mode_from_env();            // read per call (three getenv calls beside a >= 16 MB copy): tests switch modes in-process
+  const size_t min_bytes = env_mb("SD_XFER_MIN_MB", 16), chunk = env_mb("SD_XFER_CHUNK_MB", 32);
   if (mode == PLAIN || (mode == AUTO && bytes < min_bytes)) return plain(ctx, dst, src, bytes, kind);
   if (mode == REGISTER) {
     const int rc = registered(ctx, dst, src, bytes, kind);

@@ -151,3 +151,37 @@ def test_degenerate_bonds_i_equals_j_are_accepted_as_the_reference_accepts_them(
         out = np.empty_like(psi)
         pkg.apply_H(out, psi, m)
         assert np.array_equal(out, O.apply_H(r, psi))
+
+
+@pytest.mark.parametrize("cplx", [True, False])
+def test_host_transfer_modes_move_the_same_bytes(pkg, monkeypatch, cplx):
+    """csrc/xfer.cpp: the host-pointer entries copy large vectors through a ring of pinned chunks filled / drained by a team of
+    host threads (staged), or from registered caller pages (register), or with one plain hipMemcpy.  Every mode must hand
+    the kernel, and the caller, the same bytes: 11 chunks through a ring of 4 (wrap-around), a ragged last chunk, one thread and
+    many, fresh and reused result arrays."""
+    L, nup = 22, 11
+    m = pkg.XXZChain(L, nup=nup)
+    rng = np.random.default_rng(5)
+    psi = rng.standard_normal(m.N) + (1j * rng.standard_normal(m.N) if cplx else 0.0)
+    if not cplx:
+        psi = np.ascontiguousarray(psi.real)
+    monkeypatch.setenv("SD_XFER", "plain")
+    want = np.empty_like(psi)
+    pkg.apply_H(want, psi, m)
+    monkeypatch.setenv("SD_XFER_MIN_MB", "1")
+    for mode, extra in (("staged", {"SD_XFER_CHUNK_MB": "1"}), ("staged", {"SD_XFER_CHUNK_MB": "3"}), ("register", {}), ("auto", {})):
+        monkeypatch.setenv("SD_XFER", mode)
+        for k, v in extra.items():
+            monkeypatch.setenv(k, v)
+        for _ in range(2):
+            out = np.empty_like(psi)                  # fresh pages: first touched by the copy team
+            pkg.apply_H(out, psi, m)
+            assert np.array_equal(out, want), mode
+        pkg.apply_H(out, psi, m)                      # reused pages
+        assert np.array_equal(out, want), mode
+    # the recursion-level entries use the same path: psi0 in, psi(t) out
+    monkeypatch.setenv("SD_XFER", "plain")
+    a = pkg.time_evolve(m, psi, 0.1, method="chebyshev", cheb_n=6, Ebounds=(-12.0, 7.0))
+    monkeypatch.setenv("SD_XFER", "staged")
+    b = pkg.time_evolve(m, psi, 0.1, method="chebyshev", cheb_n=6, Ebounds=(-12.0, 7.0))
+    assert np.array_equal(a, b)
