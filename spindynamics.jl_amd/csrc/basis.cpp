@@ -154,20 +154,10 @@ static void xcd_order(const sd_model *m, int p, std::vector<uint32_t> &tp_io, st
     int B0 = 1;     // first bond considered as an orbit generator (two-pass probe: the bonds below belong to the other pass)
     if (const char *e = getenv("SD_XCD_ORBIT_FROM")) B0 = std::max(1, atoi(e));
     const size_t nt = tp_io.size();
-    // A wrap bond (1, j) with j in the suffix -- the periodic chain's (L, 1) -- maps tile P onto the ONE tile P ^ 1 (site 1
-    // flipped): with it, site 1 alone becomes a generator (P and P ^ 1 are queued next to each other, so the gather of the wrap
-    // bond finds the partner's rows in this XCD's L2) and the pair generators start at bond 2.  SD_XCD_WRAP=0 disables.
-    bool wrap = false;
-    {
-      const char *e = getenv("SD_XCD_WRAP");
-      if (!(e && atoi(e) == 0) && B0 == 1) {
-        const int nn = count_nn_hops(m);
-        for (size_t h = (size_t)nn; h < m->hop_i.size() && !wrap; ++h) {
-          const int i = m->hop_i[h], j = m->hop_j[h];
-          wrap = (i == 1 && j > p) || (j == 1 && i > p);
-        }
-      }
-    }
+    // (Tried: with a wrap bond (1, j), j in the suffix -- the periodic chain's (L, 1) -- site 1 alone as an extra generator, so
+    // that P and P ^ 1 are queued next to each other and the wrap bond's gather finds its partner tile in L2.  Periodic L=28 /
+    // L=30: 0.775 / 3.127 ms with it, 0.770 / 3.117 without -- no gain, removed; profiles/ablation_r03.md section 5.)
+    const bool wrap = false;
     const int Bp = wrap ? 2 : B0, FOp = wrap ? std::max(FO - 1, 0) : FO;
     // canonical orbit representative: chosen pairs set to (up, down) (site 1 down with a wrap bond); member id = what is flipped
     auto canon = [&](uint32_t P, int *member_out) {

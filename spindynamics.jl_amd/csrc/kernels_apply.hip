@@ -58,7 +58,7 @@ namespace {
 // Accumulation order per row is the reference's bond order 1..L-1.  When every
 // NN hop amplitude is a power of two (XXZChain default 0.5) J*psi is exact and
 // acc + J*psi is evaluated with one fma (bit-identical to the unfused form).
-// minimum waves per SIMD the register allocation must allow (build-time experiments: -DSD_LB_C128=6 -DSD_LB_F64=5)
+// minimum waves per SIMD the register allocation must allow (build-time experiments: -DSD_LB_C128=6 -DSD_LB_F64=5 spill)
 #ifndef SD_LB_C128
 #define SD_LB_C128 4
 #endif
@@ -148,17 +148,6 @@ __global__ __launch_bounds__(BLOCK, (NC == 2 ? SD_LB_C128 : SD_LB_F64)) void k_a
     fb.lo = rl(my_lo, ln); fb.n = rl(my_n, ln);
     return fb;
   };
-  // The next flippable far bond in ascending order, or -- when none is left -- an EMPTY one: a window of zero rows over the
-  // tile's own rows with amplitude 0, whose loads touch no memory and return 0.  Issuing it unconditionally keeps the number
-  // of loads in flight known to the compiler at every wait (a conditional issue made every wait a full drain, i.e. no
-  // overlap between the two stream register sets at all: ablation_r03.md section 3).
-  auto take_bond = [&](uint64_t &m_, bool &valid) {
-    valid = m_ != 0;
-    FarBond fb;
-    if (valid) { const int ln = __builtin_ctzll(m_); m_ &= m_ - 1; fb = get_bond(ln); }
-    else { fb.base = base; fb.J = 0.0; fb.lo = 0; fb.n = 0; }
-    return fb;
-  };
   // rows outside [lo, lo+n) wrap to a huge unsigned offset or exceed n*ES: the load returns 0 and J*0 leaves acc unchanged
   auto issue = [&](const FarBond &fb, V(&v)[R]) {
     // partner tile lives in the owned rows, or (sharded plans) in the halo imported from its owner
@@ -172,10 +161,11 @@ __global__ __launch_bounds__(BLOCK, (NC == 2 ? SD_LB_C128 : SD_LB_F64)) void k_a
   SD_STAMP(1);
   // first far bond in flight before the own rows have even arrived
   V va[R], vb[R];
+  FarBond fa{}, fbb{};
   uint64_t mk = fmask;
-  bool have_a = false, have_b = false;
-  FarBond fa = take_bond(mk, have_a), fbb{};
-  issue(fa, va);
+  bool have_a = false;
+  auto next_lane = [&](uint64_t &m_) { const int ln = __builtin_ctzll(m_); m_ &= m_ - 1; return ln; };   // ascending bond order
+  if (mk) { fa = get_bond(next_lane(mk)); issue(fa, va); have_a = true; }
 
   // ---- diagonal (needs own) ----
   V acc[R];
@@ -215,24 +205,20 @@ __global__ __launch_bounds__(BLOCK, (NC == 2 ? SD_LB_C128 : SD_LB_F64)) void k_a
   // its own clock and one wave's LDS/VALU phase overlaps its neighbours' memory phase.
   __syncthreads();
   // ---- 3. far bonds: ping-pong pipeline, accumulation in bond order ----
-  // Two bonds per turn, a fixed number of turns (known from the ballot): each turn issues the other set's loads -- a real bond
-  // or the EMPTY one -- before it consumes its own, so R loads stay in flight across every accumulation and every wait is a
-  // counted one.  1 + 2*turns bonds are taken, at least one more than there are: the list always ends with an EMPTY bond,
-  // consumed after the loop (adds J*v = 0*0: acc unchanged up to the sign of a zero), which keeps its loads from being sunk
-  // or dropped and the counts static on every path.
-  // (at least one turn, so that the loop is straight-line code on every path: a tile without any far hop runs it on EMPTY bonds)
-  int turns = (__popcll(fmask) + 1) >> 1;
-  if (turns < 1) turns = 1;
-  do {
-    fbb = take_bond(mk, have_b); issue(fbb, vb);
+  // (The issues are conditional, so the compiler cannot count the loads in flight and drains them all before each
+  // accumulation: the two register sets overlap less than the source suggests.  Three rewrites with counted waits -- loads
+  // always issued, EMPTY bonds at the end -- were measured and lose or tie: profiles/ablation_r03.md section 3.)
+  while (have_a) {
+    bool have_b = false;
+    if (mk) { fbb = get_bond(next_lane(mk)); issue(fbb, vb); have_b = true; }
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[r] = accum<FMA>(acc[r], fa.J, va[r]);
-    fa = take_bond(mk, have_a); issue(fa, va);
+    have_a = false;
+    if (!have_b) break;
+    if (mk) { fa = get_bond(next_lane(mk)); issue(fa, va); have_a = true; }
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[r] = accum<FMA>(acc[r], fbb.J, vb[r]);
-  } while (--turns > 0);
-#pragma unroll
-  for (int r = 0; r < R; ++r) acc[r] = accum<FMA>(acc[r], fa.J, va[r]);
+  }
   SD_STAMP(3);
   SD_STAMP(4);
 
@@ -431,17 +417,12 @@ __global__ __launch_bounds__(256, 4) void k_apply_fulltile(sd_dev_model dm, doub
 #pragma unroll
     for (int r = 0; r < R; ++r) buf_load(v[r], rs, ioff[r] - lo_b);
   };
-  // the next flippable stream bond in ascending order, or an EMPTY one (zero rows, amplitude 0: loads return 0, no traffic)
-  auto take_bond = [&](uint64_t &m_) {
-    FarBond fb;
-    if (m_ != 0) { const int ln = __builtin_ctzll(m_); m_ &= m_ - 1; fb = get_bond(ln); }
-    else { fb.base = base; fb.J = 0.0; fb.lo = 0; fb.n = 0; }
-    return fb;
-  };
   V va[R], vb[R];
+  FarBond fa{}, fbb{};
   uint64_t mk = fmask;
-  FarBond fa = take_bond(mk), fbb{};
-  issue(fa, va);
+  bool have_a = false;
+  auto next_lane = [&](uint64_t &m_) { const int ln = __builtin_ctzll(m_); m_ &= m_ - 1; return ln; };
+  if (mk) { fa = get_bond(next_lane(mk)); issue(fa, va); have_a = true; }
 
   V acc[R];
 #pragma unroll
@@ -466,19 +447,18 @@ __global__ __launch_bounds__(256, 4) void k_apply_fulltile(sd_dev_model dm, doub
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[r] = accum<FMA>(acc[r], J, v[r]);
   }
-  // streams, ascending bond order: two per turn, loads always issued (EMPTY bonds at the end), see k_apply_tiled
-  int turns = (__popcll(fmask) + 1) >> 1;
-  if (turns < 1) turns = 1;
-  do {
-    fbb = take_bond(mk); issue(fbb, vb);
+  // streams, ascending bond order
+  while (have_a) {
+    bool have_b = false;
+    if (mk) { fbb = get_bond(next_lane(mk)); issue(fbb, vb); have_b = true; }
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[r] = accum<FMA>(acc[r], fa.J, va[r]);
-    fa = take_bond(mk); issue(fa, va);
+    have_a = false;
+    if (!have_b) break;
+    if (mk) { fa = get_bond(next_lane(mk)); issue(fa, va); have_a = true; }
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[r] = accum<FMA>(acc[r], fbb.J, vb[r]);
-  } while (--turns > 0);
-#pragma unroll
-  for (int r = 0; r < R; ++r) acc[r] = accum<FMA>(acc[r], fa.J, va[r]);
+  }
   // remaining (general) bonds: idx' = idx ^ (two bits)
   for (int h = nn; h < dm.n_hop; ++h) {
     const int bi = dm.hop_i[h] - 1, bj = dm.hop_j[h] - 1;

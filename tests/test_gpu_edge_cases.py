@@ -179,9 +179,10 @@ def test_host_transfer_modes_move_the_same_bytes(pkg, monkeypatch, cplx):
             assert np.array_equal(out, want), mode
         pkg.apply_H(out, psi, m)                      # reused pages
         assert np.array_equal(out, want), mode
-    # the recursion-level entries use the same path: psi0 in, psi(t) out
+    # the recursion-level entries use the same path: psi0 in, psi(t) out (Chebyshev takes ComplexF64 only, as the reference)
+    psic = psi.astype(np.complex128)
     monkeypatch.setenv("SD_XFER", "plain")
-    a = pkg.time_evolve(m, psi, 0.1, method="chebyshev", cheb_n=6, Ebounds=(-12.0, 7.0))
+    a = pkg.time_evolve(m, psic, 0.1, method="chebyshev", cheb_n=6, Ebounds=(-12.0, 7.0))
     monkeypatch.setenv("SD_XFER", "staged")
-    b = pkg.time_evolve(m, psi, 0.1, method="chebyshev", cheb_n=6, Ebounds=(-12.0, 7.0))
+    b = pkg.time_evolve(m, psic, 0.1, method="chebyshev", cheb_n=6, Ebounds=(-12.0, 7.0))
     assert np.array_equal(a, b)
