@@ -81,6 +81,12 @@ int sd_ctx_set_kpm_doubling(sd_ctx *ctx, int on);
  * does (src/KPM_Sqw.jl:218-252).  The copied row differs from a recomputed one by the rounding of exp(iqr) only (<= 1e-13
  * on S).  Never used with a caller's operator (sd_ctx_set_apply_callback). */
 int sd_ctx_set_kpm_pair_q(sd_ctx *ctx, int on);
+/* sd_lanczos_groundstate re-orthogonalises H v_j against v_1 .. v_{j-1} (src/Lanczos.jl:116-124).  on != 0 (default): in blocks
+ * of 8 columns -- the coefficients of a block are its dots with w as it stands when the block begins (classical Gram-Schmidt
+ * inside a block, modified between blocks), one pass over w per block instead of per column.  With v_k orthonormal to rounding
+ * the coefficients differ from the reference's column-by-column chain by O(eps |coeff|): E0 to 1e-12, the vector to 1e-8.
+ * on == 0: the reference's order, column by column. */
+int sd_ctx_set_gs_blocked(sd_ctx *ctx, int on);
 /* Operator applications (built-in H or the caller's operator) that the recursion-level entry points have queued on this
  * context since it was created: one per recursion step.  The difference across a call says how many steps it really ran
  * (e.g. how soon a queued Lanczos recursion noticed a breakdown). */

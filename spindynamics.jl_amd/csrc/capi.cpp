@@ -208,6 +208,12 @@ int sd_ctx_set_kpm_doubling(sd_ctx *ctx, int on) {
 
 int64_t sd_ctx_apply_count(const sd_ctx *ctx) { return ctx ? ctx->n_applies : -1; }
 
+int sd_ctx_set_gs_blocked(sd_ctx *ctx, int on) {
+  if (!ctx) return SD_EARG;
+  ctx->gs_blocked = on ? 1 : 0;
+  return SD_OK;
+}
+
 int sd_ctx_set_kpm_pair_q(sd_ctx *ctx, int on) {
   if (!ctx) return SD_EARG;
   ctx->kpm_pair_q = on ? 1 : 0;

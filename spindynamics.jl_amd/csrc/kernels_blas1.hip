@@ -82,6 +82,66 @@ __global__ __launch_bounds__(64 * SD_MDOT_MAXC) void k_mdot_reduce(const double 
   if (lane == 0 && c < nc) dst[c] = a;
 }
 
+// Blocked Gram-Schmidt link (lanczos_groundstate, src/Lanczos.jl:116-124, default form):
+//   w -= sum_{c < nc1} coef[c] * V1[:,c]      (coefficients on the device: the dots of the previous pass)
+//   partial sums of V2[:,c] . w_new  for c < nc2  (the next block's coefficients, or the column of alpha_j)
+// One read-modify-write of w per nc1 + nc2 column reads, where the sequential chain (k_sub_dot) passes over w once per column.
+// Per element the subtraction runs in column order with the arithmetic of the sequential form (x - c*v).
+constexpr int SD_BGS_B = 8;
+__global__ __launch_bounds__(BS) void k_proj_dots(double *__restrict__ w, const double *__restrict__ V1, int64_t ld, int nc1,
+                                                  const double *__restrict__ coef_dev, const double *__restrict__ V2, int nc2,
+                                                  int64_t N, double *__restrict__ partials) {
+  __shared__ double red[BS / 64][SD_BGS_B];
+  double cf[SD_BGS_B], acc[SD_BGS_B];
+#pragma unroll
+  for (int c = 0; c < SD_BGS_B; ++c) { cf[c] = c < nc1 ? coef_dev[c] : 0.0; acc[c] = 0.0; }
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const bool vec = (ld % 2 == 0) && !(((uintptr_t)w | (uintptr_t)V1 | (uintptr_t)V2) & 15);
+  const int64_t n2 = vec ? N / 2 : 0;
+  double2 *w2 = (double2 *)w;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
+    double2 x = w2[i];
+#pragma unroll
+    for (int c = 0; c < SD_BGS_B; ++c)
+      if (c < nc1) { const double2 v = ((const double2 *)(V1 + (int64_t)c * ld))[i]; x.x = x.x - cf[c] * v.x; x.y = x.y - cf[c] * v.y; }
+    if (nc1 > 0) w2[i] = x;
+#pragma unroll
+    for (int c = 0; c < SD_BGS_B; ++c)
+      if (c < nc2) { const double2 v = ((const double2 *)(V2 + (int64_t)c * ld))[i]; acc[c] += v.x * x.x + v.y * x.y; }
+  }
+  for (int64_t i = 2 * n2 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += stride) {
+    double x = w[i];
+#pragma unroll
+    for (int c = 0; c < SD_BGS_B; ++c)
+      if (c < nc1) x = x - cf[c] * V1[(int64_t)c * ld + i];
+    if (nc1 > 0) w[i] = x;
+#pragma unroll
+    for (int c = 0; c < SD_BGS_B; ++c)
+      if (c < nc2) acc[c] += V2[(int64_t)c * ld + i] * x;
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int c = 0; c < SD_BGS_B; ++c) {
+    double a = acc[c];
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, 64);
+    if (lane == 0) red[wv][c] = a;
+  }
+  __syncthreads();
+  if (threadIdx.x < SD_BGS_B) {
+    double a = 0.0;
+    for (int k = 0; k < BS / 64; ++k) a += red[k][threadIdx.x];
+    partials[(size_t)blockIdx.x * SD_BGS_B + threadIdx.x] = a;
+  }
+}
+__global__ __launch_bounds__(64 * SD_BGS_B) void k_bgs_reduce(const double *__restrict__ partials, int nb, int nc,
+                                                              double *__restrict__ dst) {
+  const int c = threadIdx.x >> 6, lane = threadIdx.x & 63;     // one wave per column, fixed order
+  double a = 0.0;
+  for (int b = lane; b < nb; b += 64) a += partials[(size_t)b * SD_BGS_B + c];
+  for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, 64);
+  if (lane == 0 && c < nc) dst[c] = a;
+}
+
 // One link of the modified Gram-Schmidt chain of lanczos_groundstate (src/Lanczos.jl:116-124) without a host round trip:
 //   if (v_sub) w -= (*s_dev) * v_sub;      then   partial sums of  v_dot . w   (reduced into a device scalar by k_reduce_to)
 // The next link reads that scalar on the device.  Same element order per thread as k_dot<1> / k_ew2 when the vectors are
@@ -349,6 +409,42 @@ int sd_k_mgs_chain(sd_ctx *ctx, double *w, const double *V, int64_t ld, int ncol
     hipLaunchKernelGGL(k_sub_dot, dim3(nb), dim3(BS), 0, ctx->stream, w, k > 0 ? V + (int64_t)(k - 1) * ld : nullptr,
                        ctx->d_scalars + slot, V + (int64_t)k * ld, N, ctx->d_partials);
     hipLaunchKernelGGL(k_reduce_to, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_partials, nb, ctx->d_scalars + slot);
+  }
+  SD_HIP(ctx, hipGetLastError());
+  return SD_OK;
+}
+
+int sd_k_bgs_chain(sd_ctx *ctx, double *w, const double *V, int64_t ld, int ncols, int64_t N, int slot) {
+  // Blocked form of sd_k_mgs_chain: the columns 0..ncols-2 are projected out of w in blocks of SD_BGS_B -- the coefficients of
+  // a block are its dots with w as it stands when the block begins (classical Gram-Schmidt inside a block, modified between
+  // blocks) -- then dot(V[:,ncols-1], w) -> d_scalars[slot].  Every pass updates w with one block and forms the dots of the
+  // next: about 2 column reads per column and 2/SD_BGS_B passes over w, against 4 vector streams per column of the
+  // sequential chain.  No host synchronisation inside.
+  if (ncols <= 0) return SD_OK;
+  const int nb = (int)std::min<int64_t>(RED_BLOCKS, std::max<int64_t>(1, (N / 2 + BS - 1) / BS));
+  int rc = sd_ensure_partials(ctx, (size_t)nb * SD_BGS_B + 4 * SD_BGS_B); if (rc) return rc;
+  double *coef[2] = {ctx->d_partials + (size_t)nb * SD_BGS_B, ctx->d_partials + (size_t)nb * SD_BGS_B + 2 * SD_BGS_B};
+  const int nproj = ncols - 1;
+  const double *vlast = V + (int64_t)(ncols - 1) * ld;
+  int cur = 0;
+  // first pass: dots only (nothing to subtract yet)
+  {
+    const int nc2 = nproj > 0 ? std::min(SD_BGS_B, nproj) : 1;
+    const double *V2 = nproj > 0 ? V : vlast;
+    double *dst = nproj > 0 ? coef[cur] : ctx->d_scalars + slot;
+    hipLaunchKernelGGL(k_proj_dots, dim3(nb), dim3(BS), 0, ctx->stream, w, V, ld, 0, coef[cur], V2, nc2, N, ctx->d_partials);
+    hipLaunchKernelGGL(k_bgs_reduce, dim3(1), dim3(64 * SD_BGS_B), 0, ctx->stream, ctx->d_partials, nb, nc2, dst);
+  }
+  for (int c0 = 0; c0 < nproj; c0 += SD_BGS_B) {
+    const int nc1 = std::min(SD_BGS_B, nproj - c0), c1 = c0 + nc1;
+    const bool more = c1 < nproj;
+    const int nc2 = more ? std::min(SD_BGS_B, nproj - c1) : 1;
+    const double *V2 = more ? V + (int64_t)c1 * ld : vlast;
+    double *dst = more ? coef[cur ^ 1] : ctx->d_scalars + slot;
+    hipLaunchKernelGGL(k_proj_dots, dim3(nb), dim3(BS), 0, ctx->stream, w, V + (int64_t)c0 * ld, ld, nc1, coef[cur], V2, nc2, N,
+                       ctx->d_partials);
+    hipLaunchKernelGGL(k_bgs_reduce, dim3(1), dim3(64 * SD_BGS_B), 0, ctx->stream, ctx->d_partials, nb, nc2, dst);
+    cur ^= 1;
   }
   SD_HIP(ctx, hipGetLastError());
   return SD_OK;

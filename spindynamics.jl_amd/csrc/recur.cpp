@@ -575,7 +575,11 @@ extern "C" int sd_lanczos_groundstate(sd_ctx *ctx, const sd_model *m, int lanc_m
     double s[2];
     // :116-124: w -= dot(V[:,k], w) V[:,k] for k = 1..j-1, then alpha_j = dot(V[:,j], w) -- one chain of fused
     // subtract-and-dot kernels whose scalars stay on the device; only alpha_j comes back to the host
-    RC(sd_k_mgs_chain(ctx, w.p, V.p, N, j, N, 4)); RC(sd_read_scalars(ctx, 4, 1, s));
+    // (default: in blocks of 8 columns, classical Gram-Schmidt inside a block -- the coefficients differ from the sequential
+    // chain's by O(eps * |coeff|), half the passes over memory; sd_ctx_set_gs_blocked(ctx, 0): the reference's column order)
+    if (ctx->gs_blocked) RC(sd_k_bgs_chain(ctx, w.p, V.p, N, j, N, 4));
+    else RC(sd_k_mgs_chain(ctx, w.p, V.p, N, j, N, 4));
+    RC(sd_read_scalars(ctx, 4, 1, s));
     alpha[j - 1] = s[0];                                                                 // :124
     RC(sd_k_sub2(ctx, w.p, vj, j == 1 ? nullptr : V.p + N * (int64_t)(j - 2), N, alpha[j - 1],
                  j == 1 ? 0.0 : beta[j - 2]));                                           // :127-129

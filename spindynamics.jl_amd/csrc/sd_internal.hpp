@@ -69,6 +69,7 @@ struct sd_ctx {
   sd_apply_fn user_apply = nullptr;   // recursion-level operator supplied by the caller (sd_ctx_set_apply_callback), or null
   void *user_apply_data = nullptr;
   int64_t n_applies = 0;    // operator applications the recursion-level entries have queued on this context (sd_ctx_apply_count)
+  int gs_blocked = 1;       // sd_ctx_set_gs_blocked: lanczos_groundstate re-orthogonalises in blocks of 8 columns (default) or column by column as the reference
   int kpm_pair_q = 1;       // sd_ctx_set_kpm_pair_q: for a real psi0 compute S(q,w) once per pair (q, 2pi - q) and copy the row
 };
 
@@ -224,6 +225,7 @@ int sd_k_build_diag(const sd_dev_model &dm, double *out);   // out[local row] = 
 int sd_k_lanczos_fold_scalars(sd_ctx *ctx, int form, const double *dot_dev, const double *n2c_dev, double *store_alpha,
                               double *store_bc);
 int sd_k_mgs_chain(sd_ctx *ctx, double *w, const double *V, int64_t ld, int ncols, int64_t N, int slot);   // MGS against V[:,0..ncols-2], then dot with V[:,ncols-1] -> d_scalars[slot]
+int sd_k_bgs_chain(sd_ctx *ctx, double *w, const double *V, int64_t ld, int ncols, int64_t N, int slot);   // the same in blocks of 8 columns (classical inside a block): ~half the passes over memory
 int sd_k_mdot(sd_ctx *ctx, const double *V, int64_t ld, int ncols, const double *y, int64_t N, double *out_host);   // out[c] = V[:,c].y (real)
 int sd_read_scalars(sd_ctx *ctx, int slot, int count, double *out);
 int sd_k_scale_div(sd_ctx *ctx, double *y, const double *x, int64_t n, double d);      // y = x / d

@@ -110,10 +110,21 @@ def test_lanczos_family_vs_oracle(pkg, O, L, nup, Jxy, Jz, bc):
     assert len(al) == len(al2) and abs(nv - nv2) <= 1e-12 * nv2
     assert np.abs(al - al2).max() <= 1e-9 and np.abs(be - be2).max() <= 1e-9   # Lanczos amplifies rounding noise
     x0 = np.random.default_rng(4).standard_normal(m.N)
-    E, gs = pkg.lanczos_groundstate(pkg.apply_H, m, lanc_m=60, psi0=x0)
     E2, gs2 = O.lanczos_groundstate(r, x0, lanc_m=60)
-    assert abs(E - E2) <= 1e-10
-    assert min(np.abs(gs - gs2).max(), np.abs(gs + gs2).max()) <= 1e-6         # eigenvector up to sign, converged part
+    # full re-orthogonalisation in blocks of 8 columns (default) and column by column (the reference's order):
+    # both within the bars of the oracle, and within 1e-12 / 1e-8 of each other
+    res = {}
+    try:
+        for blocked in (True, False):
+            m.ctx.set_gs_blocked(blocked)
+            E, gs = pkg.lanczos_groundstate(pkg.apply_H, m, lanc_m=60, psi0=x0)
+            assert abs(E - E2) <= 1e-10
+            assert min(np.abs(gs - gs2).max(), np.abs(gs + gs2).max()) <= 1e-6     # eigenvector up to sign, converged part
+            res[blocked] = (E, gs)
+    finally:
+        m.ctx.set_gs_blocked(True)
+    assert abs(res[True][0] - res[False][0]) <= 1e-12
+    assert min(np.abs(res[True][1] - res[False][1]).max(), np.abs(res[True][1] + res[False][1]).max()) <= 1e-8
 
 
 @pytest.mark.parametrize("L,nup,Jxy,Jz,bc", MODELS)
@@ -421,6 +432,25 @@ def test_user_operator_at_recursion_level(pkg, O):
     assert len(calls) == n_before and abs(2 * lo3 - lo) < 1e-10
     with pytest.raises(pkg.ArgumentError):
         pkg.lanczos_extremal("not callable", m)
+
+
+def test_blocked_gram_schmidt_chain_sizes(pkg, O):
+    """lanczos_groundstate with the blocked re-orthogonalisation across the block boundaries (1, 8, 9, 16, 17, 25 columns) and
+    an odd dimension (scalar tail of the 16-byte loop): E0 against the oracle and against the column-by-column chain."""
+    for (L, nup, lm) in ((10, 5, 2), (10, 5, 9), (10, 5, 10), (12, 6, 17), (12, 6, 18), (11, 5, 26), (13, 6, 40)):
+        m = pkg.XXZChain(L, Jz=0.8, nup=nup)
+        r = O.XXZChain(L, Jz=0.8, nup=nup)
+        x0 = np.random.default_rng(L + lm).standard_normal(m.N)
+        E2, gs2 = O.lanczos_groundstate(r, x0, lanc_m=lm)
+        try:
+            m.ctx.set_gs_blocked(True)
+            Eb, gb = pkg.lanczos_groundstate(pkg.apply_H, m, lanc_m=lm, psi0=x0)
+            m.ctx.set_gs_blocked(False)
+            Es, gss = pkg.lanczos_groundstate(pkg.apply_H, m, lanc_m=lm, psi0=x0)
+        finally:
+            m.ctx.set_gs_blocked(True)
+        assert abs(Eb - E2) <= 1e-10 and abs(Es - E2) <= 1e-10 and abs(Eb - Es) <= 1e-12, (L, nup, lm)
+        assert min(np.abs(gb - gss).max(), np.abs(gb + gss).max()) <= 1e-8, (L, nup, lm)
 
 
 def test_kpm_sqw_pairs_q_with_2pi_minus_q_for_a_real_psi0(pkg, O):
