@@ -350,3 +350,32 @@ def test_bench_gpus_n_launches_ranks_itself():
     import torch
     if not torch.cuda.is_available():
         assert r.returncode != 0          # the ranks could not create a context: the parent hands that on
+
+
+def test_julia_shim_block_structure_is_balanced():
+    """No Julia here to parse julia/SpinDynamicsMI.jl: at least every block opener (function, if, for, while, struct, module,
+    begin, let, try, do, quote, macro) must have its `end`, and (), [], {} must balance -- strings and comments removed, and
+    `for` / `if` / `end` inside brackets (comprehensions, a[end]) not counted."""
+    text = open(os.path.join(ROOT, "julia", "SpinDynamicsMI.jl")).read()
+    text = re.sub(r'"""(?:.|\n)*?"""', '""', text)
+    text = re.sub(r'"(?:\\.|[^"\\\n])*"', '""', text)
+    text = re.sub(r"#=.*?=#", "", text, flags=re.S)
+    text = re.sub(r"#[^\n]*", "", text)
+    depth = {"(": 0, "[": 0, "{": 0}
+    pairs = {")": "(", "]": "[", "}": "{"}
+    opened, closed = 0, 0
+    for tok in re.finditer(r"[()\[\]{}]|\b[A-Za-z_][A-Za-z_0-9!]*\b", text):
+        t = tok.group(0)
+        if t in depth:
+            depth[t] += 1
+        elif t in pairs:
+            depth[pairs[t]] -= 1
+            assert depth[pairs[t]] >= 0, "unbalanced %s near offset %d" % (t, tok.start())
+        elif depth["("] == 0 and depth["["] == 0 and depth["{"] == 0:
+            if t in ("function", "if", "for", "while", "struct", "module", "begin", "let", "try", "do", "quote", "macro"):
+                # `mutable struct` is one opener; a one-line `f(x) = ...` definition has no keyword at all
+                opened += 1
+            elif t == "end":
+                closed += 1
+    assert depth == {"(": 0, "[": 0, "{": 0}, depth
+    assert opened == closed, (opened, closed)
