@@ -173,6 +173,127 @@ __global__ __launch_bounds__(256) void k_obs(sd_dev_model dm, const double *__re
   }
 }
 
+// ---- one-pass forms for the tiled layouts (round 3) ----
+// A tile's rows share the "uniform" sites (sector: the prefix sites 1..p; full basis: the sites above the 2^10 rows of a
+// tile) and differ in the "variable" ones (suffix sites / the low 10 index bits).
+//   MODE 0, magnetisation: sum_rows prob * sz(site).  Variable sites: one signed add per row and site; uniform sites: the
+//     thread adds its rows' total probability of the tile, signed by the tile's bit, once per tile -- all L sites in ONE pass
+//     over psi (the chunked kernel above needs ceil(L/16) passes and 4 lane-operations per row and site).
+//   MODE 1, lag sums R_r = sum_rows prob * (L - 2 popcount(s ^ rot_r s)) / 4: popcount(s ^ rot_r s) = popcount(s ^ rot_{L-r} s),
+//     so only r = 1 .. L/2 are accumulated (R_0 = L/4 * sum prob), in 32-bit arithmetic when L <= 32: one pass as well.
+// The sums run in another order than the reference's row loop (src/Observables.jl:19-30, 56-72): tolerance 1e-13 in the tests.
+#define SD_OBS2_COLS 64
+template <int NC, bool FULL, int MODE, bool WIDE>
+__global__ __launch_bounds__(256) void k_obs2(sd_dev_model dm, const double *__restrict__ psi, double *__restrict__ partials) {
+  constexpr int NV = 16, NU = 32, NLAG = 32;
+  __shared__ double red[4][SD_OBS2_COLS];
+  double accV[MODE == 0 ? NV : 1], accU[MODE == 0 ? NU : 1], lag[MODE == 1 ? NLAG : 1];
+  double total = 0.0;
+#pragma unroll
+  for (int k = 0; k < (MODE == 0 ? NV : 1); ++k) accV[k] = 0.0;
+#pragma unroll
+  for (int k = 0; k < (MODE == 0 ? NU : 1); ++k) accU[k] = 0.0;
+#pragma unroll
+  for (int k = 0; k < (MODE == 1 ? NLAG : 1); ++k) lag[k] = 0.0;
+  const int L = dm.L;
+  const int nv = FULL ? 10 : dm.LS, nu = L - nv;           // variable / uniform site counts
+  const int vsh = FULL ? 0 : dm.p;                         // bit position of the first variable site
+  const int nl = L / 2;
+  const int64_t ntiles = FULL ? (dm.n_local >> 10) : (int64_t)dm.n_tiles;
+  for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    uint64_t ubits;                                        // the uniform sites' bits, site order, from bit 0
+    int64_t base;
+    int len;
+    const uint16_t *__restrict__ sufS = nullptr;
+    if (FULL) {
+      base = t << 10; len = 1024;
+      ubits = (uint64_t)((dm.row_lo + base) >> 10);
+    } else {
+      const uint32_t P = dm.tile_prefix[t];
+      base = dm.tile_base[t];
+      const int t2 = dm.nup - __popc(P);
+      len = (int)binom_g(dm, dm.LS, t2);
+      sufS = dm.suf_states + dm.suf_off[t2];
+      ubits = P;
+    }
+    double tsum = 0.0;
+    for (int i = threadIdx.x; i < len; i += 256) {
+      double prob;
+      if (NC == 2) { const double2 v = ((const double2 *)psi)[base + i]; prob = v.x * v.x + v.y * v.y; }
+      else { const double v = psi[base + i]; prob = v * v; }
+      const uint32_t var = FULL ? (uint32_t)i : (uint32_t)sufS[i];
+      tsum += prob;
+      if (MODE == 0) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k)
+          if (k < nv) accV[k] += ((var >> k) & 1u) ? prob : -prob;
+      } else {
+        const uint64_t s64 = FULL ? ((ubits << 10) | var) : (ubits | ((uint64_t)var << vsh));
+        if (!WIDE) {
+          const uint32_t s = (uint32_t)s64, mask = L >= 32 ? 0xffffffffu : ((1u << L) - 1u);
+#pragma unroll
+          for (int r = 1; r <= NLAG; ++r)
+            if (r <= nl) {
+              const uint32_t rot = ((s >> r) | (s << (L - r))) & mask;
+              lag[r - 1] += prob * (double)(L - 2 * (int)__popc(s ^ rot));
+            }
+        } else {
+          const uint64_t mask = ((uint64_t)1 << L) - 1;
+#pragma unroll
+          for (int r = 1; r <= NLAG; ++r)
+            if (r <= nl) {
+              const uint64_t rot = ((s64 >> r) | (s64 << (L - r))) & mask;
+              lag[r - 1] += prob * (double)(L - 2 * (int)__popcll(s64 ^ rot));
+            }
+        }
+      }
+    }
+    total += tsum;
+    if (MODE == 0) {
+#pragma unroll
+      for (int k = 0; k < NU; ++k)
+        if (k < nu) accU[k] += ((ubits >> k) & 1) ? tsum : -tsum;
+    }
+  }
+  // columns: MODE 0: [0, nv) variable sites, [16, 16+nu) uniform sites; MODE 1: [0, nl) lags 1..nl; column 63: sum prob
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  auto put = [&](int col, double a) {
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, 64);
+    if (lane == 0) red[wv][col] = a;
+  };
+  if (threadIdx.x < 4 * SD_OBS2_COLS) (&red[0][0])[threadIdx.x] = 0.0;
+  __syncthreads();
+  if (MODE == 0) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) put(k, accV[k]);
+#pragma unroll
+    for (int k = 0; k < NU; ++k) put(NV + k, accU[k]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < NLAG; ++k) put(k, lag[k]);
+  }
+  put(SD_OBS2_COLS - 1, total);
+  __syncthreads();
+  if (threadIdx.x < SD_OBS2_COLS)
+    partials[(size_t)blockIdx.x * SD_OBS2_COLS + threadIdx.x] =
+        ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+}
+
+// out[c] = sum over blocks of partials[block][c], fixed order (16 strided partial sums per column, then their sum)
+__global__ __launch_bounds__(1024) void k_obs2_reduce(const double *__restrict__ partials, int nblocks, double *__restrict__ out) {
+  __shared__ double sm[16][SD_OBS2_COLS];
+  const int c = threadIdx.x & 63, j = threadIdx.x >> 6;
+  double a = 0.0;
+  for (int b = j; b < nblocks; b += 16) a += partials[(size_t)b * SD_OBS2_COLS + c];
+  sm[j][c] = a;
+  __syncthreads();
+  if (threadIdx.x < SD_OBS2_COLS) {
+    double t = 0.0;
+    for (int jj = 0; jj < 16; ++jj) t += sm[jj][threadIdx.x];
+    out[threadIdx.x] = t;
+  }
+}
+
 __global__ __launch_bounds__(256) void k_obs_reduce(const double *__restrict__ partials, int nblocks, double *__restrict__ out) {
   // thread (k, j): accumulator k, blocks j, j+16, ... ; then a fixed-order sum over j
   __shared__ double sm[16][SD_OBS_CHUNK];
@@ -272,6 +393,44 @@ int sd_launch_observable(sd_ctx *ctx, const sd_model *m, int dtype, const void *
   if (!m->dev_ready) return sd_set_err(ctx, SD_EARG, "model has no device tables (created without a context)");
   if (dtype != SD_F64 && dtype != SD_C128) return sd_set_err(ctx, SD_EARG, "dtype must be SD_F64 or SD_C128");
   const sd_dev_model &dm = m->dm;
+  const bool tiled = m->p >= 0 && dm.n_tiles > 0 && dm.LS <= 15 && dm.p <= 32;
+  const bool fullt = m->p < 0 && m->full_ls > 0 && dm.L >= 12 && dm.L <= 40 && (dm.n_local >> 10) > 0;
+  if ((tiled || fullt) && !getenv("SD_OBS_CHUNKED")) {
+    // one pass over psi for all L sites / all lags (k_obs2)
+    const int64_t ntiles = fullt ? (dm.n_local >> 10) : (int64_t)dm.n_tiles;
+    const int nb2 = (int)std::min<int64_t>(ntiles, 2048);
+    int rc2 = sd_ensure_partials(ctx, (size_t)nb2 * SD_OBS2_COLS + SD_OBS2_COLS);
+    if (rc2) return rc2;
+    double *res = ctx->d_partials + (size_t)nb2 * SD_OBS2_COLS;
+    const bool wide = dm.L > 32, c = dtype == SD_C128;
+#define SD_OBS2_LAUNCH(NC_, FULL_, MODE_, WIDE_)                                                                              \
+    hipLaunchKernelGGL((k_obs2<NC_, FULL_, MODE_, WIDE_>), dim3(nb2), dim3(256), 0, ctx->stream, dm, (const double *)psi, ctx->d_partials)
+    if (mode == 0) {
+      if (fullt) { if (c) SD_OBS2_LAUNCH(2, true, 0, false); else SD_OBS2_LAUNCH(1, true, 0, false); }
+      else { if (c) SD_OBS2_LAUNCH(2, false, 0, false); else SD_OBS2_LAUNCH(1, false, 0, false); }
+    } else if (wide) {
+      if (fullt) { if (c) SD_OBS2_LAUNCH(2, true, 1, true); else SD_OBS2_LAUNCH(1, true, 1, true); }
+      else { if (c) SD_OBS2_LAUNCH(2, false, 1, true); else SD_OBS2_LAUNCH(1, false, 1, true); }
+    } else {
+      if (fullt) { if (c) SD_OBS2_LAUNCH(2, true, 1, false); else SD_OBS2_LAUNCH(1, true, 1, false); }
+      else { if (c) SD_OBS2_LAUNCH(2, false, 1, false); else SD_OBS2_LAUNCH(1, false, 1, false); }
+    }
+#undef SD_OBS2_LAUNCH
+    hipLaunchKernelGGL(k_obs2_reduce, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_partials, nb2, res);
+    SD_HIP(ctx, hipGetLastError());
+    double h[SD_OBS2_COLS];
+    SD_HIP(ctx, hipMemcpyAsync(h, res, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const int L = dm.L, nv = fullt ? 10 : dm.LS, nu = L - nv;
+    if (mode == 0) {
+      for (int k = 0; k < nv; ++k) out_host[(fullt ? 0 : dm.p) + k] = 0.5 * h[k];          // prob * (+-1/2)
+      for (int k = 0; k < nu; ++k) out_host[(fullt ? 10 : 0) + k] = 0.5 * h[16 + k];
+    } else {
+      out_host[0] = 0.25 * (double)L * h[SD_OBS2_COLS - 1];
+      for (int r = 1; r <= L / 2; ++r) out_host[r] = out_host[L - r] = 0.25 * h[r - 1];
+    }
+    return SD_OK;
+  }
   int nb = m->p >= 0 ? std::min(dm.n_tiles, 2048) : (int)std::min<int64_t>(2048, (dm.n_local + 255) / 256);
   if (nb < 1) nb = 1;
   int rc = sd_ensure_partials(ctx, (size_t)nb * SD_OBS_CHUNK);

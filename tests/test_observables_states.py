@@ -73,7 +73,9 @@ def test_host_initial_state_index(pkg, L, nup):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("L,nup,bc", [(4, 2, "open"), (9, 4, "open"), (12, 6, "periodic"), (16, 8, "open"), (20, 7, "open"), (9, None, "open"), (40, 2, "open")])
+@pytest.mark.parametrize("L,nup,bc", [(4, 2, "open"), (9, 4, "open"), (12, 6, "periodic"), (16, 8, "open"), (20, 7, "open"), (9, None, "open"), (40, 2, "open"),
+                                      # one-pass kernels (k_obs2): odd L, full basis with 2^10-row tiles, L > 32 (64-bit rotations)
+                                      (13, 6, "open"), (17, 5, "periodic"), (12, None, "open"), (15, None, "periodic"), (34, 3, "open")])
 def test_hip_observables_vs_oracle(pkg, O, L, nup, bc):
     m = pkg.XXZChain(L, nup=nup, boundary=bc)
     r = O.XXZChain(L, nup=nup, boundary=bc)
@@ -126,3 +128,20 @@ def test_oracle_spin_operator_known_answers(O):
     assert O.spin_operator(r, 1, "x", psi)[1] == 0.5
     assert O.spin_operator(r, 1, "y", psi)[1] == -0.5j
     assert np.all(O.spin_operator(r, 1, "minus", psi) == 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("L,nup", [(14, 7), (19, 9), (13, None), (34, 3)])
+def test_one_pass_observables_equal_the_chunked_kernels(pkg, L, nup, monkeypatch):
+    """k_obs2 (all sites / all lags in one pass over psi, uniform sites of a tile added once per tile, lags r and L-r shared)
+    against the 16-accumulators-per-pass kernels it replaces (SD_OBS_CHUNKED=1): same sums in another order, 1e-13."""
+    m = pkg.XXZChain(L, nup=nup)
+    rng = np.random.default_rng(L)
+    for cplx in (True, False):
+        psi = rng.standard_normal(m.N) + (1j * rng.standard_normal(m.N) if cplx else 0)
+        psi /= np.linalg.norm(psi)
+        monkeypatch.delenv("SD_OBS_CHUNKED", raising=False)
+        mag, cr = pkg.magnetization_per_site(psi, m), pkg.connected_correlations(psi, m)
+        monkeypatch.setenv("SD_OBS_CHUNKED", "1")
+        mag2, cr2 = pkg.magnetization_per_site(psi, m), pkg.connected_correlations(psi, m)
+        assert np.abs(mag - mag2).max() <= 1e-13 and np.abs(cr - cr2).max() <= 1e-13
