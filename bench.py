@@ -445,8 +445,11 @@ def main():
             "vs_baseline": None,
             "dtype": args.dtype,
             "data": "synthetic: counter-based N(0,1) psi keyed by (seed=%d, global index), normalised" % SEED,
-            "config": {"workload": "XXZChain(L=%d, nup=%d) open, Jxy=Jz=1, hz=0: out <- H psi, ComplexF64, N=%d; "
-                                   "%s shards, %d rank(s), halo exchange per step" % (L, nup, N, "popcount-cell" if op.mode == "class" else "basis-index-range", world),
+            "config": {"workload": "XXZChain(L=%d, nup=%d) open, Jxy=Jz=1, hz=0: out <- H psi, %s, N=%d, per-row summation in the "
+                                   "reference's order (bit-identical to the CPU oracle; the order-relaxed two-pass form was probed and is "
+                                   "slower: DESIGN section 5); %s shards, %d rank(s), halo exchange per step"
+                                   % (L, nup, "ComplexF64" if args.dtype == "c128" else "Float64", N,
+                                      "popcount-cell" if op.mode == "class" else "basis-index-range", world),
                        "rows_per_rank": op.n_local, "halo_rows_rank0": op.n_halo, "shard_mode": op.mode,
                        "device_path": model.device_path,
                        "halo_routing": halo_routing, "per_rank_ms": per_rank, "c_rccl_path_ms": c_rccl},
