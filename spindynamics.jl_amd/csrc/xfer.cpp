@@ -189,6 +189,13 @@ int xfer(sd_ctx *ctx, void *dst, const void *src, size_t bytes, hipMemcpyKind ki
     const int rc = registered(ctx, dst, src, bytes, kind);
     if (rc >= 0) return rc;
   }
+  // no pinned memory to be had (locked-memory limit of the process): one plain copy instead of a failed call
+  if (ensure_ring(ctx, chunk) != SD_OK) {
+    (void)hipGetLastError();
+    sd_xfer_release(ctx);
+    ctx->err.clear();
+    return plain(ctx, dst, src, bytes, kind);
+  }
   // prior work on the stream (the producer of a device source, the consumer of a device destination) is ordered before the
   // DMA because the DMA is queued on the same stream
   return kind == hipMemcpyHostToDevice ? staged_h2d(ctx, (char *)dst, (const char *)src, bytes, chunk)

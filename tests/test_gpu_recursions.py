@@ -437,7 +437,7 @@ def test_user_operator_at_recursion_level(pkg, O):
 def test_blocked_gram_schmidt_chain_sizes(pkg, O):
     """lanczos_groundstate with the blocked re-orthogonalisation across the block boundaries (1, 8, 9, 16, 17, 25 columns) and
     an odd dimension (scalar tail of the 16-byte loop): E0 against the oracle and against the column-by-column chain."""
-    for (L, nup, lm) in ((10, 5, 2), (10, 5, 9), (10, 5, 10), (12, 6, 17), (12, 6, 18), (11, 5, 26), (13, 6, 40)):
+    for (L, nup, lm) in ((10, 5, 2), (10, 5, 9), (10, 5, 10), (12, 6, 17), (12, 6, 18), (11, 5, 26), (13, 6, 40), (7, 3, 10), (15, 7, 12)):   # C(7,3), C(15,7) odd
         m = pkg.XXZChain(L, Jz=0.8, nup=nup)
         r = O.XXZChain(L, Jz=0.8, nup=nup)
         x0 = np.random.default_rng(L + lm).standard_normal(m.N)
