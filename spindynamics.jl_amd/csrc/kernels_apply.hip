@@ -59,6 +59,9 @@ namespace {
 // NN hop amplitude is a power of two (XXZChain default 0.5) J*psi is exact and
 // acc + J*psi is evaluated with one fma (bit-identical to the unfused form).
 // minimum waves per SIMD the register allocation must allow (build-time experiments: -DSD_LB_C128=6 -DSD_LB_F64=5 spill)
+#ifndef SD_SKIP_DEAD_ROWS
+#define SD_SKIP_DEAD_ROWS 1
+#endif
 #ifndef SD_LB_C128
 #define SD_LB_C128 4
 #endif
@@ -149,18 +152,34 @@ __global__ __launch_bounds__(BLOCK, (NC == 2 ? SD_LB_C128 : SD_LB_F64)) void k_a
     return fb;
   };
   // rows outside [lo, lo+n) wrap to a huge unsigned offset or exceed n*ES: the load returns 0 and J*0 leaves acc unchanged
+  // Row groups of this wave that lie wholly beyond the tile's last row (a 792-row tile in a 4 x 256 geometry leaves the waves
+  // 1..3 of the last group without a row) issue no far-bond loads at all: their stream registers stay zero.  The range check
+  // would return zeros for them anyway, but every such load still costs the address unit its cycles (TA busy 70 % of the
+  // launch, ablation_r03.md section 5): 19 % of the stream loads of a 792-row tile, 6 % of a 924-row tile.
+  uint32_t live = 0;
+  if (SD_SKIP_DEAD_ROWS) {
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      if (r * BLOCK + (tid & ~63) < len) live |= 1u << r;
+    live = (uint32_t)__builtin_amdgcn_readfirstlane((int)live);
+  }
   auto issue = [&](const FarBond &fb, V(&v)[R]) {
     // partner tile lives in the owned rows, or (sharded plans) in the halo imported from its owner
     const V *__restrict__ pb = (halo && fb.base >= dm.n_local) ? halo + (fb.base - dm.n_local) : psi + fb.base;
     const __amdgpu_buffer_rsrc_t rs = make_rsrc(pb, (uint32_t)fb.n * ES);
     const uint32_t rel = off0 - (uint32_t)fb.lo * ES;      // wraps for rows below the window: the range check returns 0
 #pragma unroll
-    for (int r = 0; r < R; ++r) buf_load(v[r], rs, rel + (uint32_t)(r * BLOCK) * ES);
+    for (int r = 0; r < R; ++r)
+      if (!SD_SKIP_DEAD_ROWS || ((live >> r) & 1u)) buf_load(v[r], rs, rel + (uint32_t)(r * BLOCK) * ES);
   };
 
   SD_STAMP(1);
   // first far bond in flight before the own rows have even arrived
   V va[R], vb[R];
+  if (SD_SKIP_DEAD_ROWS) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) { va[r] = V{}; vb[r] = V{}; }
+  }
   FarBond fa{}, fbb{};
   uint64_t mk = fmask;
   bool have_a = false;
