@@ -156,8 +156,10 @@ __global__ __launch_bounds__(BLOCK, (NC == 2 ? SD_LB_C128 : SD_LB_F64)) void k_a
   // 1..3 of the last group without a row) issue no far-bond loads at all: their stream registers stay zero.  The range check
   // would return zeros for them anyway, but every such load still costs the address unit its cycles (TA busy 70 % of the
   // launch, ablation_r03.md section 5): 19 % of the stream loads of a 792-row tile, 6 % of a 924-row tile.
+  // Float64 only: measured -2...3 % there (L=30 1.640 -> 1.609 ms, L=32 6.89 -> 6.67), but +5 % for ComplexF64 (11.24 -> 11.87 ms).
+  constexpr bool SKIP_DEAD = SD_SKIP_DEAD_ROWS && NC == 1;
   uint32_t live = 0;
-  if (SD_SKIP_DEAD_ROWS) {
+  if (SKIP_DEAD) {
 #pragma unroll
     for (int r = 0; r < R; ++r)
       if (r * BLOCK + (tid & ~63) < len) live |= 1u << r;
@@ -170,13 +172,13 @@ __global__ __launch_bounds__(BLOCK, (NC == 2 ? SD_LB_C128 : SD_LB_F64)) void k_a
     const uint32_t rel = off0 - (uint32_t)fb.lo * ES;      // wraps for rows below the window: the range check returns 0
 #pragma unroll
     for (int r = 0; r < R; ++r)
-      if (!SD_SKIP_DEAD_ROWS || ((live >> r) & 1u)) buf_load(v[r], rs, rel + (uint32_t)(r * BLOCK) * ES);
+      if (!SKIP_DEAD || ((live >> r) & 1u)) buf_load(v[r], rs, rel + (uint32_t)(r * BLOCK) * ES);
   };
 
   SD_STAMP(1);
   // first far bond in flight before the own rows have even arrived
   V va[R], vb[R];
-  if (SD_SKIP_DEAD_ROWS) {
+  if (SKIP_DEAD) {
 #pragma unroll
     for (int r = 0; r < R; ++r) { va[r] = V{}; vb[r] = V{}; }
   }
