@@ -68,9 +68,7 @@ namespace {
 #ifndef SD_LB_F64
 #define SD_LB_F64 4
 #endif
-// HALO = false: the instantiation of unsharded plans and interior-only launches -- no partner tile lives in a halo buffer, so the
-// per-bond "owned rows or halo?" test (a 64-bit compare and two address candidates per far bond and wave) is compiled out.
-template <int NC, int R, int BLOCK, bool FMA, bool DIAG = false, bool HALO = true>
+template <int NC, int R, int BLOCK, bool FMA, bool DIAG = false>
 __global__ __launch_bounds__(BLOCK, (NC == 2 ? SD_LB_C128 : SD_LB_F64)) void k_apply_tiled(sd_dev_model dm, double *__restrict__ out_,
                                                        const double *__restrict__ psi_, int epi, sd_epi_args ea,
                                                        double *__restrict__ partials, int max_len) {
@@ -82,7 +80,7 @@ __global__ __launch_bounds__(BLOCK, (NC == 2 ? SD_LB_C128 : SD_LB_F64)) void k_a
   double *red = reinterpret_cast<double *>(lbin + 16 * SD_BIN_STRIDE);
 
   const V *__restrict__ psi = reinterpret_cast<const V *>(psi_);
-  const V *__restrict__ halo = HALO ? reinterpret_cast<const V *>(ea.halo) : nullptr;
+  const V *__restrict__ halo = reinterpret_cast<const V *>(ea.halo);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int tix = blockIdx.x + dm.tile_off;
@@ -629,9 +627,6 @@ int launch_tiled_cfg(sd_ctx *ctx, const sd_dev_model &dm, int nt, size_t shmem, 
                      const sd_epi_args &ea, int max_len) {
   // the stamped (DIAG) instantiation exists for one configuration only and is reached through sd_debug_phase_profile
   void (*kern)(sd_dev_model, double *, const double *, int, sd_epi_args, double *, int) = k_apply_tiled<NC, R, BLOCK, FMA>;
-  // no halo buffer in play (unsharded plans; SD_NO_HALO_VARIANT=1 keeps the general instantiation for A/B runs)
-  static const bool no_variant = getenv("SD_NO_HALO_VARIANT") != nullptr;
-  if (!ea.halo && !no_variant) kern = k_apply_tiled<NC, R, BLOCK, FMA, false, false>;
   // ... and for the SD_DEBUG_SKIP timing ablations: the production instantiations carry no run-time debug branches
   if constexpr (NC == 2 && FMA && (BLOCK == 256 || BLOCK == 128 || BLOCK == 64))
     if (dm.stamps || dm.dbg) kern = k_apply_tiled<NC, R, BLOCK, FMA, true>;
