@@ -60,9 +60,10 @@ def self_launch(n):
     env.setdefault("OMP_NUM_THREADS", "1")
     sys.stderr.write("bench.py: starting %d ranks: %s\n" % (n, " ".join(cmd)))
     proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
-    for ln in proc.stdout:            # rank 0's JSON line (and nothing else) arrives on stdout
-        sys.stdout.write(ln)
-        sys.stdout.flush()
+    for ln in proc.stdout:            # rank 0's JSON line goes to stdout; anything else a rank or its transport prints, to stderr
+        out = sys.stdout if ln.lstrip().startswith("{") else sys.stderr
+        out.write(ln)
+        out.flush()
     raise SystemExit(proc.wait())
 
 
