@@ -109,6 +109,25 @@ def deal(orbs, name):
         srt = sorted(range(len(orbs)), key=lambda i: (gray_rank(orbs[i][0] >> (p - k), k), i))
         for o, i in enumerate(srt):
             q[(o // oc) % 8].extend(orbs[i][1])
+    elif name.startswith("col"):
+        # column groups: all tiles that agree on the prefix sites a+1..p (and are in this length class) back to back on one XCD --
+        # a group is closed under the prefix bonds 1..a-1 (the structure of the two-pass probe's P2, with whole tiles as segments)
+        oc = int(name.split("x")[1]) if "x" in name else 1
+        bypop = "p" in name.split("x")[0][3:] or name.startswith("colp")
+        a = int("".join(ch for ch in name[3:].split("x")[0] if ch.isdigit()))
+        grp = {}
+        for P in tiles:
+            key = (P >> a, popc(P & ((1 << a) - 1))) if bypop else (P >> a)
+            grp.setdefault(key, []).append(P)
+        for o, (_, ps) in enumerate(grp.items()):
+            q[(o // oc) % 8].extend(ps)
+    elif name.startswith("asc") or name.startswith("pasc"):
+        # tiles in ascending order of the prefix taken as an integer (site 1 = bit 0 varies fastest: the transpose of the memory
+        # order), optionally split by the filling of the whole prefix first (pasc), dealt to the XCDs in runs of K tiles
+        K = int(name.lstrip("pasc"))
+        srt = sorted(tiles, key=(lambda P: (popc(P), P)) if name.startswith("pasc") else (lambda P: P))
+        for i, P in enumerate(srt):
+            q[(i // K) % 8].append(P)
     else:
         raise SystemExit("unknown order " + name)
     return q
