@@ -29,18 +29,22 @@ TRAFFIC_SOURCES = ["spindynamics.jl_amd/csrc/kernels_apply.hip", "spindynamics.j
 
 def kernel_source_hash():
     """Hash of what decides the apply kernel's memory traffic: the kernel and its device helpers, the plan / tile-order code, and
-    the device-side structs of sd_internal.hpp (not the rest of that header: host-only fields do not change a kernel)."""
+    the device-side structs of sd_internal.hpp (not the rest of that header: host-only fields do not change a kernel), with
+    comments and white space removed."""
     import hashlib
     import re
     h = hashlib.sha256()
     for rel in TRAFFIC_SOURCES:
         with open(os.path.join(ROOT, rel), "rb") as f:
             data = f.read()
+        text = data.decode()
         if rel.endswith("sd_internal.hpp"):
-            text = data.decode()
             parts = [re.search(r"struct %s \{.*?\n\};" % name, text, re.S) for name in ("sd_tile_rec", "sd_dev_model", "sd_epi_args")]
-            data = "\n".join(m.group(0) if m else "" for m in parts).encode()
-        h.update(data)
+            text = "\n".join(m.group(0) if m else "" for m in parts)
+        # comments and white space do not change a kernel: a note added to a source must not invalidate the measurement
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        text = re.sub(r"//[^\n]*", "", text)
+        h.update(" ".join(text.split()).encode())
     return h.hexdigest()[:16]
 
 

@@ -154,34 +154,10 @@ static void xcd_order(const sd_model *m, int p, std::vector<uint32_t> &tp_io, st
     int B0 = 1;     // first bond considered as an orbit generator (two-pass probe: the bonds below belong to the other pass)
     if (const char *e = getenv("SD_XCD_ORBIT_FROM")) B0 = std::max(1, atoi(e));
     const size_t nt = tp_io.size();
-    // "Transposed" order (SD_XCD_PASC = K > 0): the tiles of the segment sorted by (filling of the prefix, prefix taken as an
-    // integer) -- site 1 is bit 0, so the LOW sites vary fastest, the transpose of the memory order, and a hop on a low prefix
-    // bond b lands about 2^b places away -- and dealt to the XCDs in runs of K consecutive tiles: all partners under the bonds
-    // among the first ~8 sites are then within the few hundred tiles an XCD's L2 holds, whatever the configuration (the orbits
-    // catch only the flippable ODD bonds).  Modelled in profiles/l2_order_lab.py (pasc<K>), measured in ablation_r03.md section 11.
-    {
-      int K = 0;
-      if (const char *e = getenv("SD_XCD_PASC")) K = atoi(e);
-      if (K > 0 && nt >= 64 && count_nn_hops(m) > 0) {
-        std::vector<size_t> idx(nt);
-        for (size_t k = 0; k < nt; ++k) idx[k] = k;
-        std::sort(idx.begin(), idx.end(), [&](size_t a, size_t b) {
-          const int pa = __builtin_popcount(tp_io[a]), pb = __builtin_popcount(tp_io[b]);
-          return pa != pb ? pa < pb : tp_io[a] < tp_io[b];
-        });
-        std::vector<std::vector<size_t>> q(8);
-        for (size_t i = 0; i < nt; ++i) q[(i / (size_t)K) % 8].push_back(idx[i]);
-        std::vector<uint32_t> tp; std::vector<int64_t> tb;
-        tp.reserve(nt); tb.reserve(nt);
-        size_t longest = 0;
-        for (auto &v : q) longest = std::max(longest, v.size());
-        for (size_t j = 0; j < longest; ++j)
-          for (int x = 0; x < 8; ++x)
-            if (j < q[x].size()) { tp.push_back(tp_io[q[x][j]]); tb.push_back(tb_io[q[x][j]]); }
-        tp_io.swap(tp); tb_io.swap(tb);
-        return;
-      }
-    }
+    // (Tried: the "transposed" order -- tiles sorted by (filling of the prefix, prefix as an integer: site 1 varies fastest), dealt to
+    // the XCDs in runs of K.  The LRU model of profiles/l2_order_lab.py (pasc<K>) promises 25 % fewer read misses; the hardware
+    // counters show none (FETCH_SIZE +3 % / +0.4 % at K = 256 / 1024) and the apply is 1-2 % slower, 9-19 % with K >= 4096.
+    // Removed; profiles/ablation_r03.md section 11.)
     // (Tried: with a wrap bond (1, j), j in the suffix -- the periodic chain's (L, 1) -- site 1 alone as an extra generator, so
     // that P and P ^ 1 are queued next to each other and the wrap bond's gather finds its partner tile in L2.  Periodic L=28 /
     // L=30: 0.775 / 3.127 ms with it, 0.770 / 3.117 without -- no gain, removed; profiles/ablation_r03.md section 5.)
