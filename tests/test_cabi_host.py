@@ -379,3 +379,27 @@ def test_julia_shim_block_structure_is_balanced():
                 closed += 1
     assert depth == {"(": 0, "[": 0, "{": 0}, depth
     assert opened == closed, (opened, closed)
+
+
+def test_bench_helpers_hash_and_cores(tmp_path, monkeypatch):
+    """bench.py: the stamp of the PMC traffic figure follows the code of the apply kernel, not its comments; the CPU baseline's
+    thread count is what the process is allowed (affinity mask, cgroup quota), at least one."""
+    import bench
+    h0 = bench.kernel_source_hash()
+    assert re.fullmatch(r"[0-9a-f]{16}", h0)
+    # the same sources with a comment and blank lines added hash alike; a code change does not
+    src = os.path.join(ROOT, bench.TRAFFIC_SOURCES[0])
+    text = open(src).read()
+    fake_root = tmp_path / "r"
+    for rel in bench.TRAFFIC_SOURCES:
+        dst = fake_root / rel
+        dst.parent.mkdir(parents=True, exist_ok=True)
+        dst.write_text(open(os.path.join(ROOT, rel)).read())
+    monkeypatch.setattr(bench, "ROOT", str(fake_root))
+    assert bench.kernel_source_hash() == h0
+    (fake_root / bench.TRAFFIC_SOURCES[0]).write_text("// a note\n\n" + text.replace("\n", "\n   \n", 3) + "\n/* trailing\n comment */\n")
+    assert bench.kernel_source_hash() == h0
+    (fake_root / bench.TRAFFIC_SOURCES[0]).write_text(text.replace("__syncthreads();", "__syncthreads(); __syncthreads();", 1))
+    assert bench.kernel_source_hash() != h0
+    use, aff, quota = bench.host_cores()
+    assert 1 <= use <= aff and (quota is None or quota > 0)
