@@ -28,6 +28,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 #include "device_common.hpp"
 
@@ -295,23 +296,31 @@ __global__ __launch_bounds__(BLOCK, (NC == 2 ? SD_LB_C128 : SD_LB_F64)) void k_a
     uint32_t dw[R];   // bit a-1 set <=> suffix bond a is flippable
 #pragma unroll
     for (int r = 0; r < R; ++r) dw[r] = sig[r] ^ (sig[r] >> 1);
-    for (int a = 1; a <= LS - 1; ++a) {
-      const double J = dm.hop_J[p + a - 1];
-      const int *brow = lbin + (LS - a - 1) * SD_BIN_STRIDE;
-      int d[R];
+    // RL = row groups the loop covers (all R)
+    auto suffix_phase = [&](auto RLc) {
+      constexpr int RL = decltype(RLc)::value;
+      for (int a = 1; a <= LS - 1; ++a) {
+        const double J = dm.hop_J[p + a - 1];
+        const int *brow = lbin + (LS - a - 1) * SD_BIN_STRIDE;
+        int d[RL];
 #pragma unroll
-      for (int r = 0; r < R; ++r) d[r] = brow[__popc(sig[r] >> (a + 1))];
-      V v[R];
+        for (int r = 0; r < RL; ++r) d[r] = brow[__popc(sig[r] >> (a + 1))];
+        V v[RL];
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const bool up = (sig[r] >> (a - 1)) & 1u;
-        const bool fl = (dw[r] >> (a - 1)) & 1u;
-        const int ip = (tid + r * BLOCK) + (up ? d[r] : -d[r]);
-        v[r] = tile[fl ? ip : max_len];
+        for (int r = 0; r < RL; ++r) {
+          const bool up = (sig[r] >> (a - 1)) & 1u;
+          const bool fl = (dw[r] >> (a - 1)) & 1u;
+          const int ip = (tid + r * BLOCK) + (up ? d[r] : -d[r]);
+          v[r] = tile[fl ? ip : max_len];
+        }
+#pragma unroll
+        for (int r = 0; r < RL; ++r) acc[r] = accum<FMA>(acc[r], J, v[r]);
       }
-#pragma unroll
-      for (int r = 0; r < R; ++r) acc[r] = accum<FMA>(acc[r], J, v[r]);
-    }
+    };
+    // (Float64, dispatching on the number of live row groups -- R, R-1, R-2 -- so that dead groups skip the phase: 99 VGPRs
+    // instead of 94, a wave per SIMD lost, 1.605 -> 1.67 ms at L=30; with launch bounds for 5 waves 12 B of scratch and 1.66 ms.
+    // Not used.  The loop as a lambda alone moves ComplexF64 from 76 to 74 VGPRs and 11.24 -> 11.09 ms at L=32.)
+    suffix_phase(std::integral_constant<int, R>{});
   }
   // ---- the general bonds in list order ----
   if (have_g) {
