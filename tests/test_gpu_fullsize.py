@@ -244,3 +244,71 @@ def test_bench_plans_of_L32_every_rank_exact(pkg, world, mode):
         del psi, out, halo, op, model
         torch.cuda.empty_cache()
     assert total == 601080390
+
+
+def test_config5_recursions_on_one_rank_full_size(pkg):
+    """BASELINE config 5 (L=36, 8 ranks): the whole sharded moment recursion sd_kpm_moments_sharded at full size on the largest
+    rank (1.26 G owned rows), every piece real -- model, pack, vectors, halo, fused KPM steps, reductions -- except the wire:
+    for the uniform state every vector of the recursion is uniform, v_n = T_n(x) |F> with x = ((L-1)/4 - b)/a, so the exchange
+    callback can fill the halo with the value the peers would have sent (the first element of what this rank sends) and the
+    all-reduce callback can scale the local sums by N / n_local.  The moments must be the Chebyshev polynomials T_n(x)."""
+    import ctypes as C
+    import torch
+    from spindynamics_jl_amd import _lib
+    L, world, rank, M = 36, 8, 3, 32
+    model = pkg.XXZChain(L, nup=L // 2)
+    op = pkg.ShardedOperator(model, rank, world, exchange_fn=lambda o, p, h: None)
+    free, _ = torch.cuda.mem_get_info()
+    if free < 16 * (5 * op.n_local + op.n_halo + op.n_send) + (6 << 30):
+        pytest.skip("not enough device memory")
+    dev = torch.device("cuda")
+    N, nl = model.N, op.n_local
+    phi = op.empty(torch.complex128, dev)
+    phi.fill_(1.0 / np.sqrt(float(N)))
+    counts = {"start": 0, "reduce": 0}
+
+    def ex_start(_u, dtype, src_ptr, halo_ptr):
+        try:
+            counts["start"] += 1
+            assert dtype == _lib.SD_C128
+            src = _lib.dev_tensor(src_ptr, 2, dev)
+            halo = _lib.dev_tensor(halo_ptr, 2 * op.n_halo, dev).view(-1, 2)
+            halo.copy_(src.view(1, 2).expand_as(halo))
+            return 0
+        except Exception:
+            return 1
+
+    def allreduce(_u, vals, count):
+        counts["reduce"] += 1
+        for i in range(count):
+            vals[i] = vals[i] * (float(N) / float(nl))
+        return 0
+
+    cbs = _lib.sd_comm_callbacks(None, _lib.EXCHANGE_START_FN(ex_start), _lib.EXCHANGE_WAIT_FN(lambda _u: 0), _lib.ALLREDUCE_FN(allreduce))
+    h = C.c_void_p()
+    pkg.check(pkg.lib().sd_comm_from_callbacks(C.byref(cbs), rank, world, C.byref(h)))
+    try:
+        a, b = L / 2 + 1.0, 0.0
+        x = ((L - 1) / 4 - b) / a
+        want = np.cos(np.arange(M) * np.arccos(x))
+        model.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        for doubling in (True, False):
+            model.ctx.set_kpm_doubling(doubling)
+            mu = np.zeros(M)
+            pkg.check(pkg.lib().sd_kpm_moments_sharded(model.ctx.h, model.h, h, phi.data_ptr(), nl, M, a, b,
+                                                       mu.ctypes.data_as(C.POINTER(C.c_double))), model.ctx.h)
+            assert np.abs(mu - want).max() <= 1e-12, (doubling, np.abs(mu - want).max())
+        assert counts["start"] >= M // 2 + M - 1 and counts["reduce"] >= M
+        # the sharded Chebyshev evolution (config 4's recursion at config 5's size) on the same rank: |F> is an eigenvector,
+        # psi(t) = exp(-i (L-1)/4 t) |F> on every owned row
+        dt, E = 0.3, (L - 1) / 4
+        psit = op.empty(torch.complex128, dev)
+        pkg.check(pkg.lib().sd_chebyshev_evolve_sharded(model.ctx.h, model.h, h, phi.data_ptr(), nl, dt, 40, -(L / 2 + 1.0), L / 2 + 1.0,
+                                                        psit.data_ptr()), model.ctx.h)
+        torch.cuda.synchronize()
+        ref = np.exp(-1j * E * dt) / np.sqrt(float(N))
+        assert float((psit - ref).abs().max()) <= 1e-12 * abs(ref)            # relative to an element (1/sqrt(N) = 1e-5)
+        del psit
+    finally:
+        model.ctx.set_kpm_doubling(True)
+        pkg.lib().sd_comm_destroy(h)
