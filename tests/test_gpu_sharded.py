@@ -281,3 +281,18 @@ def test_bench_starts_its_own_ranks_two_processes_one_gpu():
         assert set(("pack", "interior", "exchange_wait", "boundary", "bytes_sent_per_peer")) <= set(p)
     assert sum(p["rows_owned"] for p in per_rank) == 2704156          # C(24, 12)
     assert str(line["config"]["c_rccl_path_ms"]).startswith("not run")   # two ranks on one GPU: RCCL cannot run
+
+
+def test_bench_rccl_leg_runs_with_one_rank():
+    """bench.py's leg through the library's own RCCL communicator (config.c_rccl_path_ms) with a 1-rank NCCL process group on this
+    GPU: communicator creation from a broadcast id, ring self-test, sd_apply_sharded compared bit for bit with the torch path,
+    the timed loop and the max over ranks -- every line of the leg except what needs a peer."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "profiles", "bench_rccl_leg_one_rank.py"), "20"], cwd=root,
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-2500:]
+    assert "c_rccl_path_ms:" in r.stdout
