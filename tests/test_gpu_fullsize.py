@@ -246,6 +246,88 @@ def test_bench_plans_of_L32_every_rank_exact(pkg, world, mode):
     assert total == 601080390
 
 
+class _UniformStateComm:
+    """A callback communicator that stands in for the peers of ONE rank when every vector of a recursion is uniform (the uniform
+    state |F> is an eigenvector of H, so T_n(H)|F>, exp(-iHt)|F> are): the exchange fills the halo with the value the peers
+    would have sent -- the first element of what this rank sends --, the all-reduce scales the local sums by N / n_local."""
+
+    def __init__(self, pkg, op, N):
+        import ctypes as C
+        import torch
+        from spindynamics_jl_amd import _lib
+        self.counts = {"start": 0, "reduce": 0}
+        dev = torch.device("cuda")
+        scale = float(N) / float(op.n_local)
+
+        def ex_start(_u, dtype, src_ptr, halo_ptr):
+            try:
+                self.counts["start"] += 1
+                per = 2 if dtype == _lib.SD_C128 else 1
+                if op.n_halo:
+                    src = _lib.dev_tensor(src_ptr, per, dev)
+                    halo = _lib.dev_tensor(halo_ptr, per * op.n_halo, dev).view(-1, per)
+                    halo.copy_(src.view(1, per).expand_as(halo))
+                return 0
+            except Exception:
+                return 1
+
+        def allreduce(_u, vals, count):
+            self.counts["reduce"] += 1
+            for i in range(count):
+                vals[i] = vals[i] * scale
+            return 0
+
+        self._cbs = _lib.sd_comm_callbacks(None, _lib.EXCHANGE_START_FN(ex_start), _lib.EXCHANGE_WAIT_FN(lambda _u: 0),
+                                           _lib.ALLREDUCE_FN(allreduce))
+        self.h = C.c_void_p()
+        self._pkg = pkg
+        pkg.check(pkg.lib().sd_comm_from_callbacks(C.byref(self._cbs), op.rank, op.world, C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            self._pkg.lib().sd_comm_destroy(self.h)
+            self.h = None
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_config4_sharded_recursions_every_rank_exact(pkg, world):
+    """BASELINE config 4 (L=32 Chebyshev evolution, state sharded over 2 / 4 / 8 ranks) and the sharded KPM moments, through the C
+    recursions (sd_chebyshev_evolve_sharded, sd_kpm_moments_sharded) on EVERY rank of the plans bench.py runs, one rank after
+    the other on this GPU: for the uniform state the peers' halo values and the global sums are known (_UniformStateComm), so
+    psi(t) = exp(-i (L-1) t / 4) |F> and mu_n = T_n(x) must hold on every owned row of every rank."""
+    import ctypes as C
+    import torch
+    L, M, dt = 32, 16, 0.25
+    a, b = L / 2 + 1.0, 0.0
+    x = ((L - 1) / 4 - b) / a
+    want = np.cos(np.arange(M) * np.arccos(x))
+    total = 0
+    for rank in range(world):
+        model = pkg.XXZChain(L, nup=L // 2)
+        op = pkg.ShardedOperator(model, rank, world, exchange_fn=lambda o, p, h: None)
+        comm = _UniformStateComm(pkg, op, model.N)
+        try:
+            phi = op.empty(torch.complex128, "cuda")
+            phi.fill_(1.0 / np.sqrt(float(model.N)))
+            model.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+            mu = np.zeros(M)
+            pkg.check(pkg.lib().sd_kpm_moments_sharded(model.ctx.h, model.h, comm.h, phi.data_ptr(), op.n_local, M, a, b,
+                                                       mu.ctypes.data_as(C.POINTER(C.c_double))), model.ctx.h)
+            assert np.abs(mu - want).max() <= 1e-12, (world, rank, np.abs(mu - want).max())
+            psit = op.empty(torch.complex128, "cuda")
+            pkg.check(pkg.lib().sd_chebyshev_evolve_sharded(model.ctx.h, model.h, comm.h, phi.data_ptr(), op.n_local, dt, 30, -a, a,
+                                                            psit.data_ptr()), model.ctx.h)
+            torch.cuda.synchronize()
+            ref = np.exp(-1j * (L - 1) / 4 * dt) / np.sqrt(float(model.N))
+            assert float((psit - ref).abs().max()) <= 1e-12 * abs(ref), (world, rank)
+            total += op.n_local
+        finally:
+            comm.close()
+        del phi, psit, op, model
+        torch.cuda.empty_cache()
+    assert total == 601080390
+
+
 def test_config5_recursions_on_one_rank_full_size(pkg):
     """BASELINE config 5 (L=36, 8 ranks): the whole sharded moment recursion sd_kpm_moments_sharded at full size on the largest
     rank (1.26 G owned rows), every piece real -- model, pack, vectors, halo, fused KPM steps, reductions -- except the wire:
@@ -265,28 +347,8 @@ def test_config5_recursions_on_one_rank_full_size(pkg):
     N, nl = model.N, op.n_local
     phi = op.empty(torch.complex128, dev)
     phi.fill_(1.0 / np.sqrt(float(N)))
-    counts = {"start": 0, "reduce": 0}
-
-    def ex_start(_u, dtype, src_ptr, halo_ptr):
-        try:
-            counts["start"] += 1
-            assert dtype == _lib.SD_C128
-            src = _lib.dev_tensor(src_ptr, 2, dev)
-            halo = _lib.dev_tensor(halo_ptr, 2 * op.n_halo, dev).view(-1, 2)
-            halo.copy_(src.view(1, 2).expand_as(halo))
-            return 0
-        except Exception:
-            return 1
-
-    def allreduce(_u, vals, count):
-        counts["reduce"] += 1
-        for i in range(count):
-            vals[i] = vals[i] * (float(N) / float(nl))
-        return 0
-
-    cbs = _lib.sd_comm_callbacks(None, _lib.EXCHANGE_START_FN(ex_start), _lib.EXCHANGE_WAIT_FN(lambda _u: 0), _lib.ALLREDUCE_FN(allreduce))
-    h = C.c_void_p()
-    pkg.check(pkg.lib().sd_comm_from_callbacks(C.byref(cbs), rank, world, C.byref(h)))
+    comm = _UniformStateComm(pkg, op, N)
+    h, counts = comm.h, comm.counts
     try:
         a, b = L / 2 + 1.0, 0.0
         x = ((L - 1) / 4 - b) / a
@@ -311,4 +373,4 @@ def test_config5_recursions_on_one_rank_full_size(pkg):
         del psit
     finally:
         model.ctx.set_kpm_doubling(True)
-        pkg.lib().sd_comm_destroy(h)
+        comm.close()
