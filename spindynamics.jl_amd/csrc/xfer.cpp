@@ -35,7 +35,14 @@ struct sd_xfer_team {
   int nthreads = 1;
 
   explicit sd_xfer_team(int n) : nthreads(n) {
-    for (int t = 1; t < n; ++t) workers.emplace_back([this, t] { loop(t); });
+    try {
+      for (int t = 1; t < n; ++t) workers.emplace_back([this, t] { loop(t); });
+    } catch (...) {            // a destructor is not run for a half-built object: stop and join what did start, then hand the failure on
+      { std::lock_guard<std::mutex> lk(mu); stop = true; }
+      cv_work.notify_all();
+      for (auto &w : workers) w.join();
+      throw;
+    }
   }
   ~sd_xfer_team() {
     { std::lock_guard<std::mutex> lk(mu); stop = true; }
@@ -116,7 +123,12 @@ int ensure_ring(sd_ctx *ctx, size_t chunk) {
   if (!ctx->xfer_team) {
     int nt = getenv("SD_XFER_THREADS") ? atoi(getenv("SD_XFER_THREADS")) : std::min(16, allowed_cores());
     if (nt < 1) nt = 1;
-    ctx->xfer_team = new sd_xfer_team(nt);
+    // thread creation can fail (process / cgroup limits): never let that unwind through the C ABI -- copy with the calling thread alone
+    try {
+      ctx->xfer_team = new sd_xfer_team(nt);
+    } catch (...) {
+      try { ctx->xfer_team = new sd_xfer_team(1); } catch (...) { ctx->xfer_team = nullptr; return sd_set_err(ctx, SD_ENOMEM, "host copy team"); }
+    }
   }
   return SD_OK;
 }
