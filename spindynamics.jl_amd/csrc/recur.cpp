@@ -15,6 +15,9 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <new>
+#include <stdexcept>
+#include <string>
 #include <vector>
 
 #include "sd_internal.hpp"
@@ -22,6 +25,18 @@
 namespace {
 
 #define RC(x) do { int rc__ = (x); if (rc__) return rc__; } while (0)
+// No C++ exception may cross the C ABI: a failed host allocation (std::vector of the m x m work, std::string of a message) inside a
+// recursion comes back as a status.
+#define SD_ABI_GUARD(ctx, call)                                                                              \
+  try {                                                                                                       \
+    return (call);                                                                                            \
+  } catch (const std::bad_alloc &) {                                                                          \
+    return (ctx) ? sd_set_err((ctx), SD_ENOMEM, "out of host memory inside the call") : SD_ENOMEM;           \
+  } catch (const std::exception &e__) {                                                                       \
+    return (ctx) ? sd_set_err((ctx), SD_EINTERNAL, std::string("unexpected exception: ") + e__.what()) : SD_EINTERNAL; \
+  } catch (...) {                                                                                             \
+    return (ctx) ? sd_set_err((ctx), SD_EINTERNAL, "unexpected exception") : SD_EINTERNAL;                   \
+  }
 
 struct DBuf {   // device work vector, taken from / returned to the context's pool
   double *p = nullptr;
@@ -494,7 +509,7 @@ static int energy_bounds_core(Op &op, int lanc_m, const void *psi0_a, const void
   return SD_OK;
 }
 
-extern "C" int sd_lanczos_extremal(sd_ctx *ctx, const sd_model *m, int lanc_m, double tol, const void *psi0,
+static int sd_lanczos_extremal_impl(sd_ctx *ctx, const sd_model *m, int lanc_m, double tol, const void *psi0,
                                    uint64_t seed, int negate, double *emin, double *emax) {
   Op op; RC(op.init(ctx, m, nullptr));
   if (!emin || !emax) return sd_set_err(ctx, SD_EARG, "null output");
@@ -502,8 +517,12 @@ extern "C" int sd_lanczos_extremal(sd_ctx *ctx, const sd_model *m, int lanc_m, d
   RC(start_vector_op(op, v.p, psi0, false, 2 * op.n, seed));
   return extremal_dev(op, lanc_m, tol, v.p, negate, emin, emax);
 }
+extern "C" int sd_lanczos_extremal(sd_ctx *ctx, const sd_model *m, int lanc_m, double tol, const void *psi0,
+                                   uint64_t seed, int negate, double *emin, double *emax) {
+  SD_ABI_GUARD(ctx, sd_lanczos_extremal_impl(ctx, m, lanc_m, tol, psi0, seed, negate, emin, emax));
+}
 
-extern "C" int sd_lanczos_extremal_sharded(sd_ctx *ctx, const sd_model *m, sd_comm *comm, int lanc_m, double tol,
+static int sd_lanczos_extremal_sharded_impl(sd_ctx *ctx, const sd_model *m, sd_comm *comm, int lanc_m, double tol,
                                            const void *psi0_dev, uint64_t seed, int negate, double *emin, double *emax) {
   Op op; RC(op.init(ctx, m, comm));
   if (!emin || !emax) return sd_set_err(ctx, SD_EARG, "null output");
@@ -511,22 +530,34 @@ extern "C" int sd_lanczos_extremal_sharded(sd_ctx *ctx, const sd_model *m, sd_co
   RC(start_vector_op(op, v.p, psi0_dev, true, 2 * op.n, seed));
   return extremal_dev(op, lanc_m, tol, v.p, negate, emin, emax);
 }
+extern "C" int sd_lanczos_extremal_sharded(sd_ctx *ctx, const sd_model *m, sd_comm *comm, int lanc_m, double tol,
+                                           const void *psi0_dev, uint64_t seed, int negate, double *emin, double *emax) {
+  SD_ABI_GUARD(ctx, sd_lanczos_extremal_sharded_impl(ctx, m, comm, lanc_m, tol, psi0_dev, seed, negate, emin, emax));
+}
 
-extern "C" int sd_energy_bounds(sd_ctx *ctx, const sd_model *m, int lanc_m, const void *psi0_a, const void *psi0_b,
+static int sd_energy_bounds_impl(sd_ctx *ctx, const sd_model *m, int lanc_m, const void *psi0_a, const void *psi0_b,
                                 uint64_t seed, double *Emin, double *Emax) {
   Op op; RC(op.init(ctx, m, nullptr));
   if (!Emin || !Emax) return sd_set_err(ctx, SD_EARG, "null output");
   return energy_bounds_core(op, lanc_m, psi0_a, psi0_b, false, seed, Emin, Emax);
 }
+extern "C" int sd_energy_bounds(sd_ctx *ctx, const sd_model *m, int lanc_m, const void *psi0_a, const void *psi0_b,
+                                uint64_t seed, double *Emin, double *Emax) {
+  SD_ABI_GUARD(ctx, sd_energy_bounds_impl(ctx, m, lanc_m, psi0_a, psi0_b, seed, Emin, Emax));
+}
 
-extern "C" int sd_energy_bounds_sharded(sd_ctx *ctx, const sd_model *m, sd_comm *comm, int lanc_m, uint64_t seed,
+static int sd_energy_bounds_sharded_impl(sd_ctx *ctx, const sd_model *m, sd_comm *comm, int lanc_m, uint64_t seed,
                                         double *Emin, double *Emax) {
   Op op; RC(op.init(ctx, m, comm));
   if (!Emin || !Emax) return sd_set_err(ctx, SD_EARG, "null output");
   return energy_bounds_core(op, lanc_m, nullptr, nullptr, true, seed, Emin, Emax);
 }
+extern "C" int sd_energy_bounds_sharded(sd_ctx *ctx, const sd_model *m, sd_comm *comm, int lanc_m, uint64_t seed,
+                                        double *Emin, double *Emax) {
+  SD_ABI_GUARD(ctx, sd_energy_bounds_sharded_impl(ctx, m, comm, lanc_m, seed, Emin, Emax));
+}
 
-extern "C" int sd_apply_sharded(sd_ctx *ctx, const sd_model *m, sd_comm *comm, int dtype, void *out_dev, const void *psi_dev,
+static int sd_apply_sharded_impl(sd_ctx *ctx, const sd_model *m, sd_comm *comm, int dtype, void *out_dev, const void *psi_dev,
                                 int64_t n_local, int overlap) {
   if (!ctx) return SD_EARG;
   if (!m || !out_dev || !psi_dev) return sd_set_err(ctx, SD_EARG, "null argument");
@@ -541,8 +572,12 @@ extern "C" int sd_apply_sharded(sd_ctx *ctx, const sd_model *m, sd_comm *comm, i
   SD_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the halo / send buffers go back to the pool
   return SD_OK;
 }
+extern "C" int sd_apply_sharded(sd_ctx *ctx, const sd_model *m, sd_comm *comm, int dtype, void *out_dev, const void *psi_dev,
+                                int64_t n_local, int overlap) {
+  SD_ABI_GUARD(ctx, sd_apply_sharded_impl(ctx, m, comm, dtype, out_dev, psi_dev, n_local, overlap));
+}
 
-extern "C" int sd_dot_sharded(sd_ctx *ctx, sd_comm *comm, int dtype, const void *x, const void *y, int64_t n_local,
+static int sd_dot_sharded_impl(sd_ctx *ctx, sd_comm *comm, int dtype, const void *x, const void *y, int64_t n_local,
                               double *out2) {
   if (!ctx) return SD_EARG;
   if (!x || !y || !out2 || n_local < 0) return sd_set_err(ctx, SD_EARG, "bad argument");
@@ -552,8 +587,12 @@ extern "C" int sd_dot_sharded(sd_ctx *ctx, sd_comm *comm, int dtype, const void 
   RC(sd_comm_allreduce_dev(ctx, comm, ctx->d_scalars + 4, 2));
   return sd_read_scalars(ctx, 4, 2, out2);
 }
+extern "C" int sd_dot_sharded(sd_ctx *ctx, sd_comm *comm, int dtype, const void *x, const void *y, int64_t n_local,
+                              double *out2) {
+  SD_ABI_GUARD(ctx, sd_dot_sharded_impl(ctx, comm, dtype, x, y, n_local, out2));
+}
 
-extern "C" int sd_lanczos_groundstate(sd_ctx *ctx, const sd_model *m, int lanc_m, double tol, double orth_tol,
+static int sd_lanczos_groundstate_impl(sd_ctx *ctx, const sd_model *m, int lanc_m, double tol, double orth_tol,
                                       const double *psi0, uint64_t seed, double *E0, double *psi_gs, int *m_actual_out) {
   Op op; RC(op.init(ctx, m, nullptr));
   if (!E0 || !psi_gs) return sd_set_err(ctx, SD_EARG, "null output");
@@ -618,8 +657,12 @@ extern "C" int sd_lanczos_groundstate(sd_ctx *ctx, const sd_model *m, int lanc_m
   if (m_actual_out) *m_actual_out = m_actual;
   return SD_OK;
 }
+extern "C" int sd_lanczos_groundstate(sd_ctx *ctx, const sd_model *m, int lanc_m, double tol, double orth_tol,
+                                      const double *psi0, uint64_t seed, double *E0, double *psi_gs, int *m_actual_out) {
+  SD_ABI_GUARD(ctx, sd_lanczos_groundstate_impl(ctx, m, lanc_m, tol, orth_tol, psi0, seed, E0, psi_gs, m_actual_out));
+}
 
-extern "C" int sd_lanczos_tridiag(sd_ctx *ctx, const sd_model *m, const void *v, int64_t n, int lanc_m, double tol,
+static int sd_lanczos_tridiag_impl(sd_ctx *ctx, const sd_model *m, const void *v, int64_t n, int lanc_m, double tol,
                                   double *alpha, double *beta, int *m_eff, double *norm_v) {
   Op op; RC(op.init(ctx, m, nullptr));
   if (n != m->N) return sd_set_err(ctx, SD_EDIM, "vector length does not match the basis dimension");
@@ -633,6 +676,10 @@ extern "C" int sd_lanczos_tridiag(sd_ctx *ctx, const sd_model *m, const void *v,
   RC(sd_k_scale_div(ctx, vc.p, vc.p, 2 * n, normv));
   *norm_v = normv;
   return tridiag_dev(op, vc.p, lanc_m, tol, alpha, beta, m_eff);
+}
+extern "C" int sd_lanczos_tridiag(sd_ctx *ctx, const sd_model *m, const void *v, int64_t n, int lanc_m, double tol,
+                                  double *alpha, double *beta, int *m_eff, double *norm_v) {
+  SD_ABI_GUARD(ctx, sd_lanczos_tridiag_impl(ctx, m, v, n, lanc_m, tol, alpha, beta, m_eff, norm_v));
 }
 
 // krylov_time_evolve; on_dev: psi0 / psit are device vectors (psit ComplexF64; may alias a ComplexF64 psi0)
@@ -721,22 +768,34 @@ static int krylov_evolve_core(Op &op, int dtype, const void *psi0, int64_t n, do
   return emit(w.p);
 }
 
-extern "C" int sd_krylov_evolve(sd_ctx *ctx, const sd_model *m, int dtype, const void *psi0, int64_t n, double dt,
+static int sd_krylov_evolve_impl(sd_ctx *ctx, const sd_model *m, int dtype, const void *psi0, int64_t n, double dt,
                                 int kry_m, void *psit) {
   Op op; RC(op.init(ctx, m, nullptr));
   return krylov_evolve_core(op, dtype, psi0, n, dt, kry_m, psit, false);
 }
+extern "C" int sd_krylov_evolve(sd_ctx *ctx, const sd_model *m, int dtype, const void *psi0, int64_t n, double dt,
+                                int kry_m, void *psit) {
+  SD_ABI_GUARD(ctx, sd_krylov_evolve_impl(ctx, m, dtype, psi0, n, dt, kry_m, psit));
+}
 
-extern "C" int sd_krylov_evolve_dev(sd_ctx *ctx, const sd_model *m, int dtype, const void *psi0_dev, int64_t n, double dt,
+static int sd_krylov_evolve_dev_impl(sd_ctx *ctx, const sd_model *m, int dtype, const void *psi0_dev, int64_t n, double dt,
                                     int kry_m, void *psit_dev) {
   Op op; RC(op.init(ctx, m, nullptr));
   return krylov_evolve_core(op, dtype, psi0_dev, n, dt, kry_m, psit_dev, true);
 }
+extern "C" int sd_krylov_evolve_dev(sd_ctx *ctx, const sd_model *m, int dtype, const void *psi0_dev, int64_t n, double dt,
+                                    int kry_m, void *psit_dev) {
+  SD_ABI_GUARD(ctx, sd_krylov_evolve_dev_impl(ctx, m, dtype, psi0_dev, n, dt, kry_m, psit_dev));
+}
 
-extern "C" int sd_krylov_evolve_sharded(sd_ctx *ctx, const sd_model *m, sd_comm *comm, int dtype, const void *psi0_dev,
+static int sd_krylov_evolve_sharded_impl(sd_ctx *ctx, const sd_model *m, sd_comm *comm, int dtype, const void *psi0_dev,
                                         int64_t n_local, double dt, int kry_m, void *psit_dev) {
   Op op; RC(op.init(ctx, m, comm));
   return krylov_evolve_core(op, dtype, psi0_dev, n_local, dt, kry_m, psit_dev, true);
+}
+extern "C" int sd_krylov_evolve_sharded(sd_ctx *ctx, const sd_model *m, sd_comm *comm, int dtype, const void *psi0_dev,
+                                        int64_t n_local, double dt, int kry_m, void *psit_dev) {
+  SD_ABI_GUARD(ctx, sd_krylov_evolve_sharded_impl(ctx, m, comm, dtype, psi0_dev, n_local, dt, kry_m, psit_dev));
 }
 
 // chebyshev_time_evolve on device vectors: psi0_dev (c128, n elements) is read, psit_dev receives psi(t); they may be the
@@ -786,25 +845,37 @@ static int chebyshev_evolve_core(Op &op, const void *psi0, bool host_in, int64_t
   return SD_OK;
 }
 
-extern "C" int sd_chebyshev_evolve(sd_ctx *ctx, const sd_model *m, const void *psi0, int64_t n, double dt, int cheb_n,
+static int sd_chebyshev_evolve_impl(sd_ctx *ctx, const sd_model *m, const void *psi0, int64_t n, double dt, int cheb_n,
                                    double Emin, double Emax, void *psit) {
   Op op; RC(op.init(ctx, m, nullptr));
   return chebyshev_evolve_core(op, psi0, true, n, dt, cheb_n, Emin, Emax, psit, true);
 }
+extern "C" int sd_chebyshev_evolve(sd_ctx *ctx, const sd_model *m, const void *psi0, int64_t n, double dt, int cheb_n,
+                                   double Emin, double Emax, void *psit) {
+  SD_ABI_GUARD(ctx, sd_chebyshev_evolve_impl(ctx, m, psi0, n, dt, cheb_n, Emin, Emax, psit));
+}
 
-extern "C" int sd_chebyshev_evolve_dev(sd_ctx *ctx, const sd_model *m, const void *psi0_dev, int64_t n, double dt, int cheb_n,
+static int sd_chebyshev_evolve_dev_impl(sd_ctx *ctx, const sd_model *m, const void *psi0_dev, int64_t n, double dt, int cheb_n,
                                        double Emin, double Emax, void *psit_dev) {
   Op op; RC(op.init(ctx, m, nullptr));
   return chebyshev_evolve_core(op, psi0_dev, false, n, dt, cheb_n, Emin, Emax, psit_dev, false);
 }
+extern "C" int sd_chebyshev_evolve_dev(sd_ctx *ctx, const sd_model *m, const void *psi0_dev, int64_t n, double dt, int cheb_n,
+                                       double Emin, double Emax, void *psit_dev) {
+  SD_ABI_GUARD(ctx, sd_chebyshev_evolve_dev_impl(ctx, m, psi0_dev, n, dt, cheb_n, Emin, Emax, psit_dev));
+}
 
-extern "C" int sd_chebyshev_evolve_sharded(sd_ctx *ctx, const sd_model *m, sd_comm *comm, const void *psi0_dev,
+static int sd_chebyshev_evolve_sharded_impl(sd_ctx *ctx, const sd_model *m, sd_comm *comm, const void *psi0_dev,
                                            int64_t n_local, double dt, int cheb_n, double Emin, double Emax, void *psit_dev) {
   Op op; RC(op.init(ctx, m, comm));
   return chebyshev_evolve_core(op, psi0_dev, false, n_local, dt, cheb_n, Emin, Emax, psit_dev, false);
 }
+extern "C" int sd_chebyshev_evolve_sharded(sd_ctx *ctx, const sd_model *m, sd_comm *comm, const void *psi0_dev,
+                                           int64_t n_local, double dt, int cheb_n, double Emin, double Emax, void *psit_dev) {
+  SD_ABI_GUARD(ctx, sd_chebyshev_evolve_sharded_impl(ctx, m, comm, psi0_dev, n_local, dt, cheb_n, Emin, Emax, psit_dev));
+}
 
-extern "C" int sd_kpm_moments(sd_ctx *ctx, const sd_model *m, const void *phi, int64_t n, int M, double a, double b,
+static int sd_kpm_moments_impl(sd_ctx *ctx, const sd_model *m, const void *phi, int64_t n, int M, double a, double b,
                               double *mu) {
   Op op; RC(op.init(ctx, m, nullptr));
   if (n != m->N) return sd_set_err(ctx, SD_EDIM, "vector length does not match the basis dimension");
@@ -813,8 +884,12 @@ extern "C" int sd_kpm_moments(sd_ctx *ctx, const sd_model *m, const void *phi, i
   RC(h2d(ctx, ph.p, phi, 2 * n));
   return moments_dev(op, ph.p, M, a, b, mu);
 }
+extern "C" int sd_kpm_moments(sd_ctx *ctx, const sd_model *m, const void *phi, int64_t n, int M, double a, double b,
+                              double *mu) {
+  SD_ABI_GUARD(ctx, sd_kpm_moments_impl(ctx, m, phi, n, M, a, b, mu));
+}
 
-extern "C" int sd_kpm_moments_sharded(sd_ctx *ctx, const sd_model *m, sd_comm *comm, const void *phi_dev, int64_t n_local,
+static int sd_kpm_moments_sharded_impl(sd_ctx *ctx, const sd_model *m, sd_comm *comm, const void *phi_dev, int64_t n_local,
                                       int M, double a, double b, double *mu) {
   Op op; RC(op.init(ctx, m, comm));
   if (n_local != op.n) return sd_set_err(ctx, SD_EDIM, "vector length does not match the local basis dimension");
@@ -822,6 +897,10 @@ extern "C" int sd_kpm_moments_sharded(sd_ctx *ctx, const sd_model *m, sd_comm *c
   RC(moments_dev(op, (const double *)phi_dev, M, a, b, mu));
   SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return SD_OK;
+}
+extern "C" int sd_kpm_moments_sharded(sd_ctx *ctx, const sd_model *m, sd_comm *comm, const void *phi_dev, int64_t n_local,
+                                      int M, double a, double b, double *mu) {
+  SD_ABI_GUARD(ctx, sd_kpm_moments_sharded_impl(ctx, m, comm, phi_dev, n_local, M, a, b, mu));
 }
 
 // kpm_sqw (src/KPM_Sqw.jl:191-256); psi0: host vector (unsharded form) or this rank's rows on the device
@@ -901,21 +980,31 @@ static int kpm_sqw_core(Op &op, int dtype, const void *psi0, bool on_dev, int64_
   return SD_OK;
 }
 
-extern "C" int sd_kpm_sqw(sd_ctx *ctx, const sd_model *m, int dtype, const void *psi0, int64_t n, const double *q, int Qn,
+static int sd_kpm_sqw_impl(sd_ctx *ctx, const sd_model *m, int dtype, const void *psi0, int64_t n, const double *q, int Qn,
                           const double *omega, int W, int have_ab, double a, double b, int kpm_m, int kernel,
                           uint64_t seed, double *Smat) {
   Op op; RC(op.init(ctx, m, nullptr));
   return kpm_sqw_core(op, dtype, psi0, false, n, q, Qn, omega, W, have_ab, a, b, kpm_m, kernel, seed, Smat);
 }
+extern "C" int sd_kpm_sqw(sd_ctx *ctx, const sd_model *m, int dtype, const void *psi0, int64_t n, const double *q, int Qn,
+                          const double *omega, int W, int have_ab, double a, double b, int kpm_m, int kernel,
+                          uint64_t seed, double *Smat) {
+  SD_ABI_GUARD(ctx, sd_kpm_sqw_impl(ctx, m, dtype, psi0, n, q, Qn, omega, W, have_ab, a, b, kpm_m, kernel, seed, Smat));
+}
 
-extern "C" int sd_kpm_sqw_sharded(sd_ctx *ctx, const sd_model *m, sd_comm *comm, int dtype, const void *psi0_dev,
+static int sd_kpm_sqw_sharded_impl(sd_ctx *ctx, const sd_model *m, sd_comm *comm, int dtype, const void *psi0_dev,
                                   int64_t n_local, const double *q, int Qn, const double *omega, int W, int have_ab, double a,
                                   double b, int kpm_m, int kernel, uint64_t seed, double *Smat) {
   Op op; RC(op.init(ctx, m, comm));
   return kpm_sqw_core(op, dtype, psi0_dev, true, n_local, q, Qn, omega, W, have_ab, a, b, kpm_m, kernel, seed, Smat);
 }
+extern "C" int sd_kpm_sqw_sharded(sd_ctx *ctx, const sd_model *m, sd_comm *comm, int dtype, const void *psi0_dev,
+                                  int64_t n_local, const double *q, int Qn, const double *omega, int W, int have_ab, double a,
+                                  double b, int kpm_m, int kernel, uint64_t seed, double *Smat) {
+  SD_ABI_GUARD(ctx, sd_kpm_sqw_sharded_impl(ctx, m, comm, dtype, psi0_dev, n_local, q, Qn, omega, W, have_ab, a, b, kpm_m, kernel, seed, Smat));
+}
 
-extern "C" int sd_lanczos_sqw(sd_ctx *ctx, const sd_model *m, int dtype, const void *psi0, int64_t n, const double *q,
+static int sd_lanczos_sqw_impl(sd_ctx *ctx, const sd_model *m, int dtype, const void *psi0, int64_t n, const double *q,
                               int Qn, const double *omega, int W, int lanc_m, double eta, int broaden, double *Smat) {
   Op op; RC(op.init(ctx, m, nullptr));
   if (n != m->N) return sd_set_err(ctx, SD_EDIM, "vector length does not match the basis dimension");
@@ -948,4 +1037,8 @@ extern "C" int sd_lanczos_sqw(sd_ctx *ctx, const sd_model *m, int dtype, const v
     if (rs) return sd_set_err(ctx, rs, "spectral_from_tridiagonal failed");
   }
   return SD_OK;
+}
+extern "C" int sd_lanczos_sqw(sd_ctx *ctx, const sd_model *m, int dtype, const void *psi0, int64_t n, const double *q,
+                              int Qn, const double *omega, int W, int lanc_m, double eta, int broaden, double *Smat) {
+  SD_ABI_GUARD(ctx, sd_lanczos_sqw_impl(ctx, m, dtype, psi0, n, q, Qn, omega, W, lanc_m, eta, broaden, Smat));
 }
