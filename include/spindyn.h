@@ -75,10 +75,10 @@ int sd_ctx_set_stream(sd_ctx *ctx, void *hip_stream);
  * mu_2n = 2<v_n|v_n> - mu_0, mu_2n+1 = 2Re<v_n|v_n+1> - mu_1 (v_n = T_n(H~)phi); on == 0 runs the reference's loop
  * (src/KPM_Sqw.jl:103-124), one moment <phi|v_k> per apply.  Same moments up to rounding. */
 int sd_ctx_set_kpm_doubling(sd_ctx *ctx, int on);
-/* sd_kpm_sqw / sd_kpm_sqw_sharded with a REAL psi0 (Float64, or ComplexF64 whose imaginary parts are all zero -- checked on
+/* sd_kpm_sqw / sd_kpm_sqw_sharded / sd_lanczos_sqw with a REAL psi0 (Float64, or ComplexF64 whose imaginary parts are all zero -- checked on
  * the device): on != 0 (default) computes the moments once per pair of momenta (q, 2 pi - q) of the list and copies the row,
- * because H is real and phi_{2pi-q} = conj(phi_q) gives the same moments; on == 0 runs every q on its own, as the reference
- * does (src/KPM_Sqw.jl:218-252).  The copied row differs from a recomputed one by the rounding of exp(iqr) only (<= 1e-13
+ * because H is real and phi_{2pi-q} = conj(phi_q) gives the same moments (and the same Lanczos coefficients); on == 0 runs every
+ * q on its own, as the reference does (src/KPM_Sqw.jl:218-252, src/LanczosSqw.jl:63-77).  The copied row differs from a recomputed one by the rounding of exp(iqr) only (<= 1e-13
  * on S).  Never used with a caller's operator (sd_ctx_set_apply_callback). */
 int sd_ctx_set_kpm_pair_q(sd_ctx *ctx, int on);
 /* sd_lanczos_groundstate re-orthogonalises H v_j against v_1 .. v_{j-1} (src/Lanczos.jl:116-124).  on != 0 (default): in blocks

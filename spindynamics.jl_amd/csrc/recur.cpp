@@ -903,6 +903,35 @@ extern "C" int sd_kpm_moments_sharded(sd_ctx *ctx, const sd_model *m, sd_comm *c
   SD_ABI_GUARD(ctx, sd_kpm_moments_sharded_impl(ctx, m, comm, phi_dev, n_local, M, a, b, mu));
 }
 
+// H is real in the S^z basis, so for a real psi0 phi_{2pi-q} = conj(phi_q): the moments mu_n and the Lanczos coefficients
+// alpha_j, beta_j of q and of 2pi - q agree, and so do the rows S(q, w).  same_as[j] = i < j when q[j] = 2 pi k - q[i] (to 8 ulp)
+// and psi0 is real -- Float64, or ComplexF64 whose imaginary parts are all zero (counted on the device, summed over the ranks) --,
+// else -1.  momenta(model) always holds both members of a pair; the reference recomputes the second row (src/KPM_Sqw.jl:218-252,
+// src/LanczosSqw.jl:63-77), which differs from the copy by the rounding of exp(iqr) only.  Not with a caller's
+// operator (it need not be real); sd_ctx_set_kpm_pair_q(ctx, 0) switches it off.
+int pair_momenta(Op &op, int dtype, const double *psic, int64_t n, const double *q, int Qn, std::vector<int> &same_as) {
+  sd_ctx *ctx = op.ctx;
+  same_as.assign((size_t)std::max(Qn, 0), -1);
+  if (!ctx->kpm_pair_q || ctx->user_apply || Qn < 2) return SD_OK;
+  bool real_psi = dtype == SD_F64;
+  if (!real_psi) {
+    RC(sd_k_imag_count(ctx, psic, n, 6));
+    RC(op.reduce(ctx->d_scalars + 6, 1));
+    double cnt[1]; RC(sd_read_scalars(ctx, 6, 1, cnt));
+    real_psi = cnt[0] == 0.0;
+  }
+  if (!real_psi) return SD_OK;
+  const double two_pi = 6.283185307179586476925286766559;
+  for (int j = 1; j < Qn; ++j)
+    for (int i = 0; i < j; ++i) {
+      if (same_as[i] >= 0) continue;
+      const double sum = q[i] + q[j], k = std::nearbyint(sum / two_pi);
+      const double tol = 8 * 2.220446049250313e-16 * std::max(two_pi, std::max(std::fabs(q[i]), std::fabs(q[j])));
+      if (std::fabs(sum - k * two_pi) <= tol) { same_as[j] = i; break; }
+    }
+  return SD_OK;
+}
+
 // kpm_sqw (src/KPM_Sqw.jl:191-256); psi0: host vector (unsharded form) or this rank's rows on the device
 static int kpm_sqw_core(Op &op, int dtype, const void *psi0, bool on_dev, int64_t n, const double *q, int Qn,
                         const double *omega, int W, int have_ab, double a, double b, int kpm_m, int kernel, uint64_t seed,
@@ -936,30 +965,9 @@ static int kpm_sqw_core(Op &op, int dtype, const void *psi0, bool on_dev, int64_
   std::vector<double> mu(kpm_m), g(kpm_m);
   sd_kpm_kernel(kpm_m, kernel, g.data());
   int rc = 0;
-  // H is real in the S^z basis, so for a real psi0 phi_{2pi-q} = conj(phi_q) and mu_n(2pi - q) = mu_n(q): every pair
-  // (q, 2pi - q) of the list -- momenta(model) always holds both -- is computed once and its row copied (DESIGN 6.10;
-  // the reference recomputes it, src/KPM_Sqw.jl:218-252, and differs from the copy by the rounding of exp(iqr) only).
-  // Not with a caller's operator (it need not be real); sd_ctx_set_kpm_pair_q(ctx, 0) switches it off.
-  std::vector<int> same_as((size_t)std::max(Qn, 0), -1);
-  if (ctx->kpm_pair_q && !ctx->user_apply && Qn > 1) {
-    bool real_psi = dtype == SD_F64;
-    if (!real_psi) {
-      RC(sd_k_imag_count(ctx, psic.p, n, 6));
-      RC(op.reduce(ctx->d_scalars + 6, 1));
-      double cnt[1]; RC(sd_read_scalars(ctx, 6, 1, cnt));
-      real_psi = cnt[0] == 0.0;
-    }
-    if (real_psi) {
-      const double two_pi = 6.283185307179586476925286766559;
-      for (int j = 1; j < Qn; ++j)
-        for (int i = 0; i < j; ++i) {
-          if (same_as[i] >= 0) continue;
-          const double sum = q[i] + q[j], k = std::nearbyint(sum / two_pi);
-          const double tol = 8 * 2.220446049250313e-16 * std::max(two_pi, std::max(std::fabs(q[i]), std::fabs(q[j])));
-          if (std::fabs(sum - k * two_pi) <= tol) { same_as[j] = i; break; }
-        }
-    }
-  }
+  // every pair (q, 2 pi - q) of the list is computed once for a real psi0 (pair_momenta)
+  std::vector<int> same_as;
+  RC(pair_momenta(op, dtype, psic.p, n, q, Qn, same_as));
   for (int iq = 0; iq < Qn; ++iq) {                                                       // :218 (serial over q)
     double *Srow = Smat + (size_t)iq * W;
     if (same_as[iq] >= 0) {
@@ -1025,8 +1033,11 @@ static int sd_lanczos_sqw_impl(sd_ctx *ctx, const sd_model *m, int dtype, const 
   const int mm = (int)std::min<int64_t>(lanc_m, n);
   std::vector<double> alpha(mm), beta(std::max(mm, 1));
   int rc = 0;
+  std::vector<int> same_as;
+  RC(pair_momenta(op, dtype, psic.p, n, q, Qn, same_as));      // real psi0: the Lanczos coefficients of q and 2 pi - q agree
   for (int iq = 0; iq < Qn; ++iq) {
     double *Srow = Smat + (size_t)iq * W;
+    if (same_as[iq] >= 0) { std::memcpy(Srow, Smat + (size_t)same_as[iq] * W, sizeof(double) * (size_t)W); continue; }
     RC(sd_launch_szq(ctx, m, SD_C128, psic.p, q[iq], phi.p));
     const double normv = norm_dev(op, phi.p, 2 * n, &rc); RC(rc);
     if (normv == 0) { for (int iw = 0; iw < W; ++iw) Srow[iw] = 0.0; continue; }          // :67-70

@@ -486,6 +486,17 @@ def test_kpm_sqw_pairs_q_with_2pi_minus_q_for_a_real_psi0(pkg, O):
         wantc = O.kpm_sqw(r, psic, q, omega, a, b, kpm_m=96)
         assert np.abs(Sc - wantc).max() <= 1e-8 * max(1.0, np.abs(wantc).max())
         assert not np.array_equal(Sc[1], Sc[L - 1])
+        # the Lanczos S(q, w) pairs the same way (equal alpha_j, beta_j for phi and conj(phi))
+        m.ctx.set_kpm_pair_q(True)
+        Sl_on = pkg.lanczos_sqw(psi, m, q, omega, lanc_m=12, eta=0.05)
+        m.ctx.set_kpm_pair_q(False)
+        Sl_off = pkg.lanczos_sqw(psi, m, q, omega, lanc_m=12, eta=0.05)
+        m.ctx.set_kpm_pair_q(True)
+        for n in range(1, L):
+            assert np.array_equal(Sl_on[n], Sl_on[L - n])
+        assert np.abs(Sl_on - Sl_off).max() <= 1e-9 * max(1.0, np.abs(Sl_off).max())
+        wl = O.lanczos_sqw(r, psi, q, omega, lanc_m=12, eta=0.05)
+        assert np.abs(Sl_on - wl).max() <= 1e-8 * max(1.0, np.abs(wl).max())
         # a list that holds q but not 2pi - q is computed as it stands
         S3 = pkg.kpm_sqw(psi, m, q[:3], omega, a=a, b=b, kpm_m=96)
         assert np.abs(S3 - want[:3]).max() <= 1e-8 * max(1.0, np.abs(want).max())
