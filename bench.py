@@ -237,6 +237,10 @@ def main():
     backend = os.environ.get("SD_BENCH_BACKEND", "nccl")   # "gloo": rehearsal of the N>1 control flow on a 1-GPU box
     if backend != "nccl":
         local_rank %= max(1, torch.cuda.device_count())
+    elif local_rank >= torch.cuda.device_count():
+        raise SystemExit("bench.py: rank %d needs GPU %d, but this node exposes %d GPU(s) -- one GPU per rank with RCCL "
+                         "(SD_BENCH_BACKEND=gloo rehearses the N > 1 control flow with all ranks on one GPU)"
+                         % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
