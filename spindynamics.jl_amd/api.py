@@ -21,7 +21,16 @@ def time_evolve(model, psi0, t, method="krylov", Ebounds=None, **kwargs):
         return solvers.krylov_time_evolve(psi0, float(t), apply_H, model, **kwargs)
     if method == "chebyshev":
         seed = kwargs.pop("seed", 0)
-        bounds = solvers.estimate_energy_bounds(apply_H, model, seed=seed) if Ebounds is None else Ebounds
+        if Ebounds is None:
+            # the reference estimates the bounds anew on every call (two 80-step Lanczos runs, src/PublicAPI.jl:68-75).  Here the
+            # start vectors come from the counter-based generator of `seed`, so the estimate for a (model, seed) is the same
+            # every time: it is computed once and kept with the model -- a loop of time steps pays for it once (at L=32: 3 s).
+            cache = model.__dict__.setdefault("_energy_bounds", {})
+            if seed not in cache:
+                cache[seed] = solvers.estimate_energy_bounds(apply_H, model, seed=seed)
+            bounds = cache[seed]
+        else:
+            bounds = Ebounds
         return solvers.chebyshev_time_evolve(psi0, float(t), apply_H, model, Ebounds=bounds, **kwargs)
     raise ArgumentError(f"unsupported time-evolution method: {method}")
 

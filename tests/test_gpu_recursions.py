@@ -502,3 +502,22 @@ def test_kpm_sqw_pairs_q_with_2pi_minus_q_for_a_real_psi0(pkg, O):
         assert np.abs(S3 - want[:3]).max() <= 1e-8 * max(1.0, np.abs(want).max())
     finally:
         m.ctx.set_kpm_pair_q(True)
+
+
+def test_time_evolve_chebyshev_estimates_its_bounds_once_per_model(pkg):
+    """time_evolve(:chebyshev) without Ebounds (src/PublicAPI.jl:68-75): the bounds come from two 80-step Lanczos runs on start
+    vectors of the counter-based generator, i.e. they are the same for every call with the same (model, seed) -- so the mirror
+    computes them once per model: the second call returns the same bits and queues only the recursion's own applies."""
+    m = pkg.XXZChain(12, nup=6, Jz=0.7)
+    psi0 = np.random.default_rng(2).standard_normal(m.N) + 1j * np.random.default_rng(3).standard_normal(m.N)
+    psi0 /= np.linalg.norm(psi0)
+    n0 = m.ctx.apply_count()
+    a = pkg.time_evolve(m, psi0, 0.2, method="chebyshev", cheb_n=20)
+    n1 = m.ctx.apply_count()
+    b = pkg.time_evolve(m, psi0, 0.2, method="chebyshev", cheb_n=20)
+    n2 = m.ctx.apply_count()
+    assert np.array_equal(a, b)
+    assert n1 - n0 > 100 and n2 - n1 <= 20          # first call: 2 x 80 Lanczos steps + 19 terms; second: the terms alone
+    bounds = pkg.estimate_energy_bounds(pkg.apply_H, m, seed=0)
+    c = pkg.time_evolve(m, psi0, 0.2, method="chebyshev", cheb_n=20, Ebounds=bounds)
+    assert np.array_equal(a, c)                     # the cached estimate is the one an explicit call gives
