@@ -154,7 +154,8 @@ def c_rccl_path(pkg, op, src, dst, steps, dist, backend, dev, rank, all_ok, on_t
     """The same steps once more through sd_apply_sharded on the library's own RCCL communicator (csrc/comm.cpp: pack,
     grouped ncclSend/ncclRecv on a second stream, interior tiles meanwhile, boundary tiles after the halo) instead of
     torch.distributed issued from Python.  Returns ms per step, or a string saying why there is no number.  If RCCL never
-    returns, a watchdog calls on_timeout() -- rank 0 prints the headline line without this figure -- and ends the process."""
+    returns, a watchdog calls on_timeout() -- rank 0 prints the headline line without this figure -- and ends the process
+    with status 3, so that the launcher and the driver see that the RCCL leg hung."""
     import ctypes as C
     import threading
     import torch
@@ -168,7 +169,8 @@ def c_rccl_path(pkg, op, src, dst, steps, dist, backend, dev, rank, all_ok, on_t
             sys.stderr.write("rank %d: the C RCCL path did not finish within %.0f s; giving up on it\n" % (rank, limit))
             sys.stderr.flush()
             on_timeout()
-            os._exit(0)
+            sys.stdout.flush()
+            os._exit(3)      # the headline line is out, but a hung collective must not read as a green run
     comm = None
     try:
         from spindynamics_jl_amd.dist import RcclComm

@@ -300,7 +300,9 @@ typedef struct sd_slab {
   int64_t global_row;       /* global basis index of the slab's first element */
 } sd_slab;
 /* Re-plans the model as shard `rank` of `nranks` (nranks == 1 restores the
- * unsharded plan).  Must be called before any apply on that model. */
+ * unsharded plan).  Must be called before any apply on that model.  On failure
+ * (SD_ENOMEM, SD_EHIP, ...) the model is left WITHOUT a plan: every later call
+ * that needs one returns SD_EARG; destroy the model (or call set_shard again). */
 int sd_model_set_shard(sd_model *m, int rank, int nranks);
 /* One KPM moment step on a shard (src/KPM_Sqw.jl:106-117), ComplexF64 device vectors of n_local elements:
  * first != 0: v_next = (H v_curr - b v_curr)/a; else v_next = 2 (H v_curr - b v_curr)/a - v_prev.

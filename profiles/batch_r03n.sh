@@ -1,5 +1,8 @@
 #!/bin/bash
 # bytes past the L2s and hit rates of the transposed tile order against the orbit order (L=32 c128)
+# HISTORICAL: SD_XCD_PASC selected a tile order that existed only in commit b4b15af and was removed in b3f5209 (measured: no
+# fewer bytes).  At any later commit no source reads the variable and all four passes measure the same orbit order; the records
+# profiles/r03/transposed_order_counters.txt and ab_transposed_order.txt can only be reproduced from a checkout of b4b15af.
 set -u
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/r03n

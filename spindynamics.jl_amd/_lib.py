@@ -215,6 +215,7 @@ class Context:
         check(lib().sd_ctx_create(device, C.byref(self.h)))
         self.device = device
         self.kpm_doubling = True      # mirror of the library's per-context flag (sd_ctx_set_kpm_doubling)
+        self._apply_cb, self._apply_owner = None, None   # a caller's operator (trampoline, weakref to the installing model)
 
     def set_stream(self, stream_ptr):
         check(lib().sd_ctx_set_stream(self.h, _vp(stream_ptr)), self.h)
@@ -232,6 +233,18 @@ class Context:
     def set_gs_blocked(self, on):
         """True (default): lanczos_groundstate re-orthogonalises in blocks of 8 columns; False: column by column (reference order)."""
         check(lib().sd_ctx_set_gs_blocked(self.h, 1 if on else 0), self.h)
+
+    def install_apply(self, cb, owner_ref):
+        """Install a ctypes APPLY_FN trampoline as this context's recursion-level operator (sd_ctx_set_apply_callback) and keep
+        it alive here, with a weak reference to the model that installed it (model.Model.set_apply)."""
+        check(lib().sd_ctx_set_apply_callback(self.h, cb, None), self.h)
+        self._apply_cb, self._apply_owner = cb, owner_ref
+
+    def clear_apply(self):
+        """Back to the built-in operator; the trampoline is released only after the library has dropped its pointer."""
+        if self.h:
+            check(lib().sd_ctx_set_apply_callback(self.h, APPLY_FN(), None), self.h)
+        self._apply_cb, self._apply_owner = None, None
 
     def apply_count(self):
         """Operator applications the recursion-level calls have queued on this context so far (one per recursion step)."""

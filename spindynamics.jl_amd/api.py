@@ -16,7 +16,10 @@ def groundstate(model, method="lanczos", **kwargs):
 
 
 def time_evolve(model, psi0, t, method="krylov", Ebounds=None, **kwargs):
-    """time_evolve(model, psi0, t; method=:krylov, Ebounds=nothing, kwargs...) -- src/PublicAPI.jl:50-88"""
+    """time_evolve(model, psi0, t; method=:krylov, Ebounds=nothing, kwargs...) -- src/PublicAPI.jl:50-88
+
+    method="chebyshev" without Ebounds: the bounds of the built-in H are estimated once per (model, seed) and kept with the
+    model (the reference re-estimates them on every call); a caller's operator on the model's context bypasses the cache."""
     if method == "krylov":
         return solvers.krylov_time_evolve(psi0, float(t), apply_H, model, **kwargs)
     if method == "chebyshev":
@@ -25,10 +28,15 @@ def time_evolve(model, psi0, t, method="krylov", Ebounds=None, **kwargs):
             # the reference estimates the bounds anew on every call (two 80-step Lanczos runs, src/PublicAPI.jl:68-75).  Here the
             # start vectors come from the counter-based generator of `seed`, so the estimate for a (model, seed) is the same
             # every time: it is computed once and kept with the model -- a loop of time steps pays for it once (at L=32: 3 s).
-            cache = model.__dict__.setdefault("_energy_bounds", {})
-            if seed not in cache:
-                cache[seed] = solvers.estimate_energy_bounds(apply_H, model, seed=seed)
-            bounds = cache[seed]
+            # The cache describes the BUILT-IN operator only: with a caller's operator installed on the model's context
+            # (model.set_apply, which also drops the cache) the bounds are estimated anew, as the reference does.
+            if getattr(model.ctx, "_apply_cb", None) is not None:
+                bounds = solvers.estimate_energy_bounds(apply_H, model, seed=seed)
+            else:
+                cache = model.__dict__.setdefault("_energy_bounds", {})
+                if seed not in cache:
+                    cache[seed] = solvers.estimate_energy_bounds(apply_H, model, seed=seed)
+                bounds = cache[seed]
         else:
             bounds = Ebounds
         return solvers.chebyshev_time_evolve(psi0, float(t), apply_H, model, Ebounds=bounds, **kwargs)

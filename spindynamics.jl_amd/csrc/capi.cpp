@@ -351,7 +351,18 @@ int sd_model_set_shard(sd_model *m, int rank, int nranks) {
   if (!m) return SD_EARG;
   std::string err;
   int rc = plan_and_upload(m, rank, nranks, err);
-  if (rc) return fail(m->ctx, rc, err);
+  if (rc) {
+    // The host tables may be partly those of the new (rank, nranks) while the device tables still describe the old plan:
+    // no kernel may run on that mixture.  The model is left without a plan -- every later call that needs one fails with
+    // SD_EARG ("model has no device tables") -- until a set_shard succeeds; the caller is expected to destroy it.
+    sd_free_device_tables(m);
+    m->dev_ready = false;
+    m->n_local = 0; m->n_halo = 0; m->n_send = 0; m->n_interior = 0;
+    m->tile_prefix.clear(); m->tile_base.clear();
+    m->recv_slabs.clear(); m->send_slabs.clear();
+    m->pack_len.clear();
+    return fail(m->ctx, rc, err);
+  }
   return SD_OK;
 }
 

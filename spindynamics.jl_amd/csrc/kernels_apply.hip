@@ -546,7 +546,7 @@ __global__ __launch_bounds__(256) void k_apply_generic(sd_dev_model dm, double *
   }
 }
 
-// epilogue alone, for H psi produced by a caller's operator (sd_model_set_apply_callback): same arithmetic per element as the
+// epilogue alone, for H psi produced by a caller's operator (sd_ctx_set_apply_callback): same arithmetic per element as the
 // fused form; out may be hpsi
 template <int NC>
 __global__ __launch_bounds__(256) void k_epilogue_only(int epi, sd_epi_args ea, int64_t n, double *out_,

@@ -50,6 +50,13 @@ class Model:
 
     def __del__(self):
         try:
+            # an operator this model installed must not outlive it: the trampoline closes over the model
+            ctx = getattr(self, "ctx", None)
+            if ctx is not None and getattr(ctx, "_apply_owner", None) is not None and ctx._apply_owner() is self:
+                ctx.clear_apply()
+        except Exception:
+            pass
+        try:
             if getattr(self, "h", None):
                 lib().sd_model_destroy(self.h)
                 self.h = None
@@ -60,20 +67,39 @@ class Model:
         return self.N
 
     def set_apply(self, fn):
-        """Install `fn(out, psi, model)` as the operator of every recursion run on this model's context (the reference's
+        """Install `fn(out, psi, model)` as the operator of every recursion run on this model's CONTEXT (the reference's
         applyH! argument; sd_ctx_set_apply_callback), or restore the built-in operator with fn=None.  out and psi are torch tensors on the
         model's device (Float64 or ComplexF64, this rank's rows), valid during the call only; fn runs with torch's current
-        stream set to the library's stream and must write H psi into out."""
+        stream set to the library's stream and must write H psi into out.
+
+        The operator belongs to the context, as in the C ABI: it replaces H for every model whose recursions run on that
+        context, so installing one on a context that other live models share (the default context is shared by all models
+        built without `ctx=`) is refused while another model's operator is installed, and the solvers' `applyH=` argument --
+        installed for the duration of one call -- is the safe route.  The trampoline is kept alive by the context and removed
+        when the installing model is garbage-collected; the cached energy bounds of time_evolve(:chebyshev) are dropped."""
+        if self.ctx is None:
+            raise ArgumentError("this model has no context: build it with ctx= to run recursions with a caller's operator")
         self._apply_err = None
+        self.__dict__.pop("_energy_bounds", None)       # bounds estimated for another operator must not be reused (api.py)
+        ctx = self.ctx
+        owner = ctx._apply_owner() if getattr(ctx, "_apply_owner", None) is not None else None
         if fn is None:
-            check(lib().sd_ctx_set_apply_callback(self.ctx.h, _lib.APPLY_FN(), None))
-            self._apply_cb = None
+            if owner is None or owner is self:
+                ctx.clear_apply()
             return
+        if owner is not None and owner is not self:
+            raise ArgumentError("another model has installed an operator on this context; give each model with its own "
+                                "operator a context of its own (Model(..., ctx=Context(device))) or pass applyH= to the solver")
+        import weakref
+        me = weakref.ref(self)
 
         def tramp(_user, dtype, out_ptr, psi_ptr, n, stream):
+            model = me()
             try:                        # an exception must not unwind through the C frames
+                if model is None:
+                    return 1
                 import torch
-                dev = torch.device("cuda", self.ctx.device)
+                dev = torch.device("cuda", ctx.device)
                 per = 2 if dtype == _lib.SD_C128 else 1
                 out = _lib.dev_tensor(out_ptr, max(int(n), 1) * per, dev)[: int(n) * per]
                 psi = _lib.dev_tensor(psi_ptr, max(int(n), 1) * per, dev)[: int(n) * per]
@@ -81,14 +107,14 @@ class Model:
                     out, psi = torch.view_as_complex(out.view(-1, 2)), torch.view_as_complex(psi.view(-1, 2))
                 st = torch.cuda.ExternalStream(int(stream), device=dev) if stream else torch.cuda.default_stream(dev)
                 with torch.cuda.stream(st):
-                    fn(out, psi, self)
+                    fn(out, psi, model)
                 return 0
             except Exception as e:
-                self._apply_err = e
+                if model is not None:
+                    model._apply_err = e
                 return 1
 
-        self._apply_cb = _lib.APPLY_FN(tramp)       # keeps the trampoline alive
-        check(lib().sd_ctx_set_apply_callback(self.ctx.h, self._apply_cb, None))
+        ctx.install_apply(_lib.APPLY_FN(tramp), me)
 
     # -- basis queries (host) --
     def states_range(self, start, count):

@@ -36,6 +36,8 @@ def _with_operator(f):
             return f(*args, **kw)
         if not callable(applyH):
             raise ArgumentError("applyH must be callable: applyH(out, psi, model)")
+        ctx = model.ctx
+        before = (ctx._apply_cb, ctx._apply_owner) if ctx is not None else (None, None)   # an operator installed with model.set_apply
         model.set_apply(applyH)
         try:
             return f(*args, **kw)
@@ -45,6 +47,8 @@ def _with_operator(f):
             raise
         finally:
             model.set_apply(None)
+            if before[0] is not None:
+                ctx.install_apply(*before)
     return g
 
 

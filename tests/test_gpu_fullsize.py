@@ -165,8 +165,10 @@ def test_config2_krylov_L28_full_size(pkg):
 
 def test_config3_kpm_moments_L30_full_size(pkg):
     """BASELINE config 3 at its real size (L=30, nup=15, 1024 moments, one momentum): mu_0 = 1 (1e-12), |mu_n| <= 1, the
-    two-moments-per-apply recursion against the reference's one-moment-per-apply loop on the first 64 moments (1e-12), and
-    the sum rule of the reconstructed S(q,w) (the reference's own test: rtol 5e-3, test/test_KPM.jl:67-91)."""
+    two-moments-per-apply recursion against the library's own one-moment-per-apply mode on the first 64 moments (1e-12 --
+    a SELF-COMPARISON of two routes through the same kernels, not an oracle check: the CPU oracle cannot follow L=30), and
+    the sum rule of the reconstructed S(q,w) (the reference's own test: rtol 5e-3, test/test_KPM.jl:67-91).
+    The oracle comparison at this recursion LENGTH (M = 1024, both routes) is tests/test_gpu_baseline_lengths.py at L=18/20."""
     import torch
     L, M = 30, 1024
     model = pkg.XXZChain(L, nup=L // 2)

@@ -434,6 +434,49 @@ def test_user_operator_at_recursion_level(pkg, O):
         pkg.lanczos_extremal("not callable", m)
 
 
+def test_set_apply_belongs_to_the_context_and_dies_with_its_model(pkg):
+    """Model.set_apply installs the operator on the model's CONTEXT (sd_ctx_set_apply_callback).  Models built without ctx=
+    share the default context, so: (i) a second model may not replace an installed operator silently; (ii) when the
+    installing model is garbage-collected the context goes back to the built-in H instead of keeping a pointer to a freed
+    thunk; (iii) the solvers' applyH= argument restores a persistently installed operator; (iv) the cached Chebyshev
+    bounds are not reused across operators."""
+    import gc
+    L, nup = 12, 6
+    m1 = pkg.XXZChain(L, nup=nup)
+    m2 = pkg.XXZChain(L, nup=nup, Jz=0.5)
+    assert m1.ctx is m2.ctx
+    psi0 = cvec(m2.N, 3)
+    psi0 /= np.linalg.norm(psi0)
+    want = pkg.lanczos_extremal(pkg.apply_H, m2, lanc_m=30, psi0=psi0)
+    calls = []
+
+    def thrice(out, psi, model):
+        calls.append(id(model))                # (no reference to the model itself: it must be collectable below)
+        pkg.apply_H(out, psi, model)
+        out.mul_(3.0)
+
+    m1.set_apply(thrice)
+    lo, hi = pkg.lanczos_extremal(pkg.apply_H, m1, lanc_m=30, psi0=psi0)       # "built-in" = whatever the context holds
+    assert calls and all(c == id(m1) for c in calls)
+    lo1, hi1 = 3 * np.array(pkg.lanczos_extremal(pkg.apply_H, pkg.XXZChain(L, nup=nup, ctx=pkg.Context(0)), lanc_m=30, psi0=psi0))
+    assert abs(lo - lo1) < 1e-9 and abs(hi - hi1) < 1e-9
+    with pytest.raises(pkg.ArgumentError):                                    # (i)
+        m2.set_apply(thrice)
+    n = len(calls)                                                            # (iii): a one-call operator, then thrice is back
+    pkg.lanczos_extremal(lambda o, p, mm: pkg.apply_H(o, p, mm), m1, lanc_m=5, psi0=psi0)
+    assert len(calls) == n
+    pkg.lanczos_extremal(pkg.apply_H, m1, lanc_m=5, psi0=psi0)
+    assert len(calls) > n
+    pkg.time_evolve(m1, psi0, 0.05, method="chebyshev", cheb_n=10)            # (iv): estimated with thrice installed, not cached
+    assert "_energy_bounds" not in m1.__dict__ or not m1.__dict__["_energy_bounds"]
+    del m1                                                                    # (ii)
+    gc.collect()
+    assert m2.ctx._apply_cb is None and m2.ctx._apply_owner is None
+    n = len(calls)
+    got = pkg.lanczos_extremal(pkg.apply_H, m2, lanc_m=30, psi0=psi0)
+    assert len(calls) == n and got == want
+
+
 def test_blocked_gram_schmidt_chain_sizes(pkg, O):
     """lanczos_groundstate with the blocked re-orthogonalisation across the block boundaries (1, 8, 9, 16, 17, 25 columns) and
     an odd dimension (scalar tail of the 16-byte loop): E0 against the oracle and against the column-by-column chain."""
