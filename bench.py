@@ -430,6 +430,7 @@ def main():
         # profiles/run_profile.sh in separate rocprofv3 passes and committed with the hash of the kernel sources it was
         # measured on.  A figure measured on other sources is not reported.
         traffic, traffic_source = None, "no PMC figure for this workload (profiles/traffic_latest.json)"
+        valu_insts = None
         tp = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tp):
             try:
@@ -437,6 +438,7 @@ def main():
                 if tj.get("L") == L and tj.get("dtype") == args.dtype and world == 1:
                     if tj.get("source_hash") == kernel_source_hash():
                         traffic = tj.get("hbm_bytes_per_launch")
+                        valu_insts = tj.get("SQ_INSTS_VALU_per_launch")
                         traffic_source = "profiles/traffic_latest.json, measured on these kernel sources (hash %s)" % tj.get("source_hash")
                     else:
                         traffic_source = "profiles/traffic_latest.json is stale (kernel sources changed since it was measured): null"
@@ -469,6 +471,16 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "frac_of_copy_ceiling": achieved / HBM_COPY_GBS,
                          "traffic": traffic, "traffic_source": traffic_source,
+                         # the verdict on the 0.60 target in numbers: how many times the algorithmic bytes
+                         # cross the fabric side of the L2s, at what rate (the chip sustains 7.4-7.9 TB/s there for gathers past
+                         # L2, MI355X_MICROARCH.md), and the time the VALU instruction stream alone would take (SQ_INSTS_VALU
+                         # wave-instructions x 4 cycles on 1024 SIMDs at 2.4 GHz) -- a second ceiling under the byte one
+                         "traffic_ratio": (traffic / alg_bytes) if traffic else None,
+                         "fabric_GBs": (traffic / (kern_ms * 1e-3) / 1e9) if traffic else None,
+                         "valu_wave_insts": valu_insts,
+                         "valu_lane_ops_per_row": (valu_insts * 64.0 / op.n_local) if valu_insts else None,
+                         "valu_issue_floor_ms": (valu_insts * 4.0 / (1024 * 2.4e9) * 1e3) if valu_insts else None,
+                         "target_frac": 0.60, "target_met": bool(achieved / HBM_PEAK_GBS >= 0.60),
                          "kernel": kernel_name(model.device_path, args.dtype),
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes},
         }

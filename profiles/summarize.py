@@ -19,18 +19,45 @@ for f in find("*kernel_stats.csv"):
         name = row.get("Name", "")[:70]
         print(f"  {name:70s} calls={row.get('Calls')} total_ns={row.get('TotalDurationNs')} avg_ns={row.get('AverageNs')} pct={row.get('Percentage')}")
 
+# registers / LDS / scratch come from the CODE OBJECT (profiles/codeobj_meta.py), not from the trace columns: rocprofv3's
+# VGPR_Count is not the kernel's allocation and its LDS_Block_Size misses dynamic LDS (evidence hygiene 9)
+try:
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import codeobj_meta
+    CO = codeobj_meta.meta()
+except Exception as e:      # tools missing: say so, never print the misleading columns instead
+    CO = {}
+    print("(code-object metadata unavailable: %r)" % (e,))
+
+
+def co_of(trace_name):
+    key = trace_name.replace("kernel void ", "void ").strip()
+    for n, d in CO.items():
+        if n == key or n.startswith(key) or key.startswith(n.split("(")[0] + "("):
+            return d
+    base = key.split("(")[0]
+    for n, d in CO.items():
+        if n.split("(")[0] == base:
+            return d
+    return None
+
+
 for f in find("*kernel_trace.csv"):
     d = defaultdict(list)
     meta = {}
     for row in csv.DictReader(open(f)):
         n = row["Kernel_Name"]
         d[n].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
-        meta[n] = (row.get("VGPR_Count"), row.get("Accum_VGPR_Count"), row.get("SGPR_Count"), row.get("LDS_Block_Size"),
-                   row.get("Workgroup_Size"), row.get("Grid_Size"))
-    print("== kernel trace:", os.path.relpath(f, out))
+        meta[n] = (row.get("Workgroup_Size"), row.get("Grid_Size"))
+    print("== kernel trace:", os.path.relpath(f, out), "(vgpr/sgpr/static-LDS/scratch/waves-per-SIMD from the code object;")
+    print("   k_apply_tiled adds DYNAMIC LDS per launch: (max_len+1)*sizeof(V) + 16*17*4 + 256 B = 16.1 KiB for 924-row c128 tiles)")
     for n, v in sorted(d.items(), key=lambda kv: -sum(kv[1])):
         v2 = sorted(v)
-        print(f"  {n[:70]:70s} n={len(v)} avg={sum(v)/len(v)/1e3:.1f}us med={v2[len(v2)//2]/1e3:.1f}us min={v2[0]/1e3:.1f}us vgpr/agpr/sgpr/lds/wg/grid={meta[n]}")
+        c = co_of(n)
+        regs = ("vgpr=%d agpr=%d sgpr=%d lds_static=%d scratch=%d waves/SIMD<=%d" % (
+            c.get("vgpr", -1), c.get("agpr", 0), c.get("sgpr", -1), c.get("lds_static", 0), c.get("scratch", 0),
+            codeobj_meta.waves_per_simd(c.get("vgpr", 512), c.get("agpr", 0)))) if c else "code object: not found"
+        print(f"  {n[:70]:70s} n={len(v)} avg={sum(v)/len(v)/1e3:.1f}us med={v2[len(v2)//2]/1e3:.1f}us min={v2[0]/1e3:.1f}us {regs} wg/grid={meta[n]}")
 
 for f in find("*counter_collection.csv"):
     acc = defaultdict(lambda: defaultdict(list))
