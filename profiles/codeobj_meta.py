@@ -15,12 +15,23 @@ LIB = os.path.join(ROOT, "spindynamics.jl_amd", "libspindyn.so")
 
 def meta(path=LIB):
     """{demangled kernel name: {vgpr, agpr, sgpr, lds_static, scratch, max_wg}}"""
+    notes = ""
     with tempfile.TemporaryDirectory() as td:
-        fat, co = os.path.join(td, "fat.bin"), os.path.join(td, "k.co")
+        fat = os.path.join(td, "fat.bin")
         subprocess.check_call([os.path.join(LLVM, "llvm-objcopy"), "-O", "binary", "--only-section=.hip_fatbin", path, fat])
-        subprocess.check_call([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o",
-                               "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--input=" + fat, "--output=" + co])
-        notes = subprocess.check_output([os.path.join(LLVM, "llvm-readelf"), "--notes", co], text=True)
+        blob = open(fat, "rb").read()
+        # one offload bundle per translation unit, concatenated in the section
+        magic = b"__CLANG_OFFLOAD_BUNDLE__"
+        starts = [m.start() for m in re.finditer(re.escape(magic), blob)] + [len(blob)]
+        for k in range(len(starts) - 1):
+            part, co = os.path.join(td, "part%d.bin" % k), os.path.join(td, "k%d.co" % k)
+            open(part, "wb").write(blob[starts[k]:starts[k + 1]])
+            r = subprocess.run([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o",
+                                "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--input=" + part, "--output=" + co],
+                               capture_output=True, text=True)
+            if r.returncode != 0 or not os.path.exists(co) or os.path.getsize(co) == 0:
+                continue
+            notes += subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", co], capture_output=True, text=True).stdout + "\n"
     out, cur = {}, {}
     keys = {".vgpr_count": "vgpr", ".agpr_count": "agpr", ".sgpr_count": "sgpr", ".group_segment_fixed_size": "lds_static",
             ".private_segment_fixed_size": "scratch", ".max_flat_workgroup_size": "max_wg"}

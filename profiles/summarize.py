@@ -30,14 +30,17 @@ except Exception as e:      # tools missing: say so, never print the misleading 
     print("(code-object metadata unavailable: %r)" % (e,))
 
 
+def _norm(n):
+    return n.replace("kernel ", "").replace("void ", "").strip()
+
+
 def co_of(trace_name):
-    key = trace_name.replace("kernel void ", "void ").strip()
+    key = _norm(trace_name)
     for n, d in CO.items():
-        if n == key or n.startswith(key) or key.startswith(n.split("(")[0] + "("):
+        if _norm(n) == key:
             return d
-    base = key.split("(")[0]
-    for n, d in CO.items():
-        if n.split("(")[0] == base:
+    for n, d in CO.items():          # a truncated trace name
+        if len(key) > 24 and (_norm(n).startswith(key) or key.startswith(_norm(n))):
             return d
     return None
 

@@ -350,7 +350,7 @@ int sd_build_plan(sd_model *m, int rank, int nranks, std::string &err) {
   if (nranks < 1 || rank < 0 || rank >= nranks) { err = "bad shard rank/nranks"; return SD_EARG; }
   m->rank = rank; m->nranks = nranks;
   m->tile_prefix.clear(); m->tile_base.clear(); m->addr.clear();
-  m->suf_states.clear(); m->suf_rank.clear(); m->suf_off.clear();
+  m->suf_states.clear(); m->suf_rank.clear(); m->suf_off.clear(); m->suf_part.clear();
   m->recv_slabs.clear(); m->send_slabs.clear();
   m->n_halo = 0; m->max_tile_len = 0;
 
@@ -424,6 +424,25 @@ int sd_build_plan(sd_model *m, int rank, int nranks, std::string &err) {
     for (int32_t i = 0; i < n; ++i) m->suf_rank[m->suf_states[m->suf_off[t] + i]] = (uint16_t)i;
   }
   m->suf_off[LS + 1] = (int32_t)m->suf_states.size();
+  // packed partner table of the suffix bonds (sd_dev_model::suf_part): 10-bit fields hold partner row + 1 <= C(12,6) = 924
+  m->suf_part.clear(); m->suf_dg.clear();
+  if (LS <= 12) {
+    m->suf_part.assign(4 * m->suf_states.size(), 0u);
+    m->suf_dg.assign(m->suf_states.size(), 0);
+    const uint32_t inner = LS >= 2 ? ((1u << (LS - 1)) - 1u) : 0u;
+    for (size_t k = 0; k < m->suf_states.size(); ++k) {
+      const uint32_t sg = m->suf_states[k];
+      uint32_t *w = m->suf_part.data() + 4 * k;
+      for (int a = 1; a <= LS - 1; ++a)
+        if (((sg >> (a - 1)) ^ (sg >> a)) & 1u) {
+          const uint32_t partner = (uint32_t)m->suf_rank[sg ^ (3u << (a - 1))] + 1u;     // same sector: same popcount
+          w[(a - 1) / 3] |= partner << (10 * ((a - 1) % 3));
+        }
+      w[3] |= (uint32_t)__builtin_popcount((sg ^ (sg >> 1)) & inner) << 20;
+      w[3] |= (sg & 1u) << 30;
+      m->suf_dg[k] = (uint8_t)(__builtin_popcount((sg ^ (sg >> 1)) & inner) | ((sg & 1u) << 4));
+    }
+  }
 
   // all feasible tiles in natural (row) order
   std::vector<TileRef> tiles;
@@ -639,6 +658,9 @@ int sd_build_plan(sd_model *m, int rank, int nranks, std::string &err) {
     if (const char *e = getenv("SD_LEN_CLASSES")) split = atoi(e) >= 2 || (split && atoi(e) != 0);   // 2: also for small plans
     int top = 0;                                     // class of the longest tile: the only class when not splitting
     while (top < SD_N_LEN_CLASS - 1 && (64 << top) * 4 < m->max_tile_len) ++top;
+    // LS > 12 (SD_SUFFIX_BITS experiments): no packed partner table; the binomial form of the kernel is built for the two
+    // largest workgroups only, one class for all tiles
+    if (m->LS > 12) { split = false; top = std::max(top, 3); }
     auto cls_of = [&](uint32_t P) {
       if (!split) return top;
       const int64_t len = B(m, m->LS, m->nup - __builtin_popcount(P));
@@ -762,6 +784,10 @@ int sd_upload_model(sd_model *m, std::string &err) {
     if ((rc = up(m, m->suf_states, &d.suf_states, err))) return rc;
     if ((rc = up(m, m->suf_off, &d.suf_off, err))) return rc;
     if ((rc = up(m, m->suf_rank, &d.suf_rank, err))) return rc;
+    if (!m->suf_part.empty()) {
+      if ((rc = up(m, m->suf_part, &d.suf_part, err))) return rc;
+      if ((rc = up(m, m->suf_dg, &d.suf_dg, err))) return rc;
+    } else { d.suf_part = nullptr; d.suf_dg = nullptr; }
     if ((rc = up(m, m->tile_gbase, &d.tile_gbase, err))) return rc;
     d.n_pack = (int)m->pack_len.size();
     if ((rc = up(m, m->pack_src, &d.pack_src, err))) return rc;
@@ -822,6 +848,12 @@ int sd_upload_model(sd_model *m, std::string &err) {
     } else {
       (void)hipGetLastError();
     }
+  }
+  // does k_apply_tiled need the rows' suffix configurations?  Not for the open chain with a cached diagonal or the uniform
+  // chain form of it: partners, the suffix's anti-parallel count and its first site all come from the packed table.
+  {
+    const bool chain_diag = d.diag_mode == 1 && (d.n_zz == 0 || (d.n_zz_nn == m->L - 1 && d.n_zz == d.n_zz_nn));
+    d.need_sig = (d.n_hop > d.nn_hops) || !(d.diag_cache || chain_diag) || !d.suf_part;
   }
   m->dev_ready = true;
   return SD_OK;

@@ -67,23 +67,36 @@ namespace {
 #define SD_LB_C128 4
 #endif
 #ifndef SD_LB_F64
-#define SD_LB_F64 4
+#define SD_LB_F64 5
 #endif
-template <int NC, int R, int BLOCK, bool FMA, bool DIAG = false>
+#ifndef SD_FAR_DEPTH
+#define SD_FAR_DEPTH 2      // register sets of the far-bond streams (1: no ping-pong, fewer registers, more waves)
+#endif
+// Rows of a thread.  A WAVE owns R*64 consecutive rows of the tile, row group r of a lane is row wave*R*64 + r*64 + lane:
+// consecutive lanes read consecutive rows (coalesced) and the R row groups of a stream differ by a compile-time byte offset
+// of r*64*sizeof(V) <= 3584, which fits the buffer instructions' 12-bit immediate -- no per-row address arithmetic.
+//
+// PK (LS <= 12, every default plan): the suffix bonds' partner rows come from the packed per-sector table dm.suf_part (one
+// 16-byte load per row, L2/L1 resident: 64 KB for all sectors): a bond costs a shift, a mask, an LDS read and the
+// multiply-add -- the binomial form (!PK: popcount, LDS binomial look-up, two bit tests, signed offset, select) cost ~14
+// lane-operations per row and bond, half of the kernel's VALU stream (VERDICT r03, weak point 5).
+template <int NC, int R, int BLOCK, bool FMA, bool PK, bool DIAG = false>
 __global__ __launch_bounds__(BLOCK, (NC == 2 ? SD_LB_C128 : SD_LB_F64)) void k_apply_tiled(sd_dev_model dm, double *__restrict__ out_,
                                                        const double *__restrict__ psi_, int epi, sd_epi_args ea,
                                                        double *__restrict__ partials, int max_len) {
   using V = typename VT<NC>::type;
   constexpr uint32_t ES = sizeof(V);
+  constexpr int WR = R * 64;                                   // rows of a wave
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  V *tile = reinterpret_cast<V *>(smem);                       // max_len rows + one all-zero row at index max_len
-  int *lbin = reinterpret_cast<int *>(smem + (size_t)(max_len + 1) * sizeof(V));
+  V *tile = reinterpret_cast<V *>(smem);                       // row 0: all zero; rows 1..len: the tile's psi
+  int *lbin = reinterpret_cast<int *>(smem + (size_t)(max_len + 1) * sizeof(V));   // !PK only
   double *red = reinterpret_cast<double *>(lbin + 16 * SD_BIN_STRIDE);
 
   const V *__restrict__ psi = reinterpret_cast<const V *>(psi_);
   const V *__restrict__ halo = reinterpret_cast<const V *>(ea.halo);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
+  const int i0 = (tid >> 6) * WR + lane;                       // the thread's first row; row group r: i0 + 64 r
   const int tix = blockIdx.x + dm.tile_off;
   const sd_tile_rec rec = dm.single_rec[tix];       // one 32-byte scalar load: no dependent table look-ups at start-up
   const uint32_t P = rec.prefix;
@@ -91,8 +104,8 @@ __global__ __launch_bounds__(BLOCK, (NC == 2 ? SD_LB_C128 : SD_LB_F64)) void k_a
   const int p = dm.p, LS = dm.LS;
   const int len = rec.len;
   const int nU = rec.nU;                            // rows whose first suffix site is up
-  const uint16_t *__restrict__ sufS = dm.suf_states + rec.suf_off;
   const int nn = dm.nn_hops;
+  const bool need_sig = !PK || dm.need_sig;
   unsigned long long *stamp = (DIAG && dm.stamps) ? dm.stamps + 8 * (size_t)tix : nullptr;
 #define SD_STAMP(k)                                                                   \
   do {                                                                                \
@@ -106,64 +119,71 @@ __global__ __launch_bounds__(BLOCK, (NC == 2 ? SD_LB_C128 : SD_LB_F64)) void k_a
   } while (0)
   SD_STAMP(0);
 
-  // ---- 1. request own rows (rows >= len read 0 through the range check) and suffix configurations ----
+  // ---- 1. request own rows (rows >= len read 0 through the range check), the partner table and, if needed, the configurations ----
   V own[R];
   uint32_t sig[R];
-  const uint32_t off0 = (uint32_t)tid * ES;   // byte offset of the thread's first row inside a tile-sized stream; row r: + r*BLOCK*ES
+  typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+  u4 pt[PK ? R : 1];
+  uint32_t dg[R];
+  const uint32_t off0 = (uint32_t)i0 * ES;   // byte offset of the thread's first row inside a tile-sized stream; row group r: + r*64*ES
   {
     const __amdgpu_buffer_rsrc_t rs = make_rsrc(psi + base, (uint32_t)len * ES);
-    const __amdgpu_buffer_rsrc_t rsig = make_rsrc(sufS, (uint32_t)len * 2u);
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int i = tid + r * BLOCK;
-      buf_load(own[r], rs, off0 + (uint32_t)(r * BLOCK) * ES);
-      sig[r] = buf_load_u16(rsig, (uint32_t)i * 2u);      // rows >= len: 0 -> no suffix bond flips, the idle row only ever reads the zero row
+    for (int r = 0; r < R; ++r) buf_load(own[r], rs, off0 + (uint32_t)(r * 64) * ES);
+    if (PK && !need_sig && !dm.diag_cache) {
+      // one byte per row: anti-parallel pairs inside the suffix (bits 0..3) and the first suffix site (bit 4)
+      const __amdgpu_buffer_rsrc_t rg = make_rsrc(dm.suf_dg + rec.suf_off, (uint32_t)len);
+#pragma unroll
+      for (int r = 0; r < R; ++r) dg[r] = (uint32_t)(unsigned char)__builtin_amdgcn_raw_buffer_load_b8(rg, (uint32_t)i0 + (uint32_t)(r * 64), 0, 0);
+    }
+    if (need_sig) {
+      const __amdgpu_buffer_rsrc_t rsig = make_rsrc(dm.suf_states + rec.suf_off, (uint32_t)len * 2u);
+#pragma unroll
+      for (int r = 0; r < R; ++r) sig[r] = buf_load_u16(rsig, (uint32_t)i0 * 2u + (uint32_t)(r * 64) * 2u);   // rows >= len: 0 -> no suffix bond flips
+    } else {
+#pragma unroll
+      for (int r = 0; r < R; ++r) sig[r] = 0;
     }
   }
 
   // ---- 2. per-wave list of flippable far bonds (lane b-1 <-> bond b <= p-1, lane p-1 <-> straddle) ----
+  // The partner bases were resolved on the host (basis.cpp, far_base; -1: the bond cannot flip): one coalesced load per wave
+  // that needs nothing but the block index, so it is in flight together with the tile record.  Everything else a bond needs is
+  // wave-uniform and scalar: its amplitude (a scalar load), and for the straddling bond the window of rows that have the hop.
   uint64_t fmask = 0;
-  int64_t my_base = 0;
-  double my_J = 0.0;
-  int my_lo = 0, my_n = len;
+  int64_t my_base = -1;
+  const uint32_t bitp = p >= 1 ? ((P >> (p - 1)) & 1u) : 0u;
   if (nn > 0 && p >= 1) {
-    // the partner bases were resolved on the host (basis.cpp, far_base): one coalesced load per wave that needs nothing but
-    // the block index, so it is in flight together with the tile record
     const int b = lane + 1;
-    if (b <= p) { my_base = dm.far_base[(size_t)tix * (size_t)p + (size_t)lane]; my_J = dm.hop_J[b - 1]; }
-    else my_base = -1;
+    if (b <= p) my_base = dm.far_base[(size_t)tix * (size_t)p + (size_t)lane];
     bool fl = my_base >= 0;
-    if (b <= p - 1) {
-      fl = fl && !(DIAG && ((dm.dbg & 1) || b <= (dm.dbg >> 8)));      // dbg >> 8 = m: prefix bonds 1..m left to another pass (two-pass probe)
-    } else if (b == p) {
-      // bit p of P up:   our rows with first suffix site down (i >= nU) <-> partner rows i - nU
-      // bit p of P down: our rows with first suffix site up   (i <  nU) <-> partner rows nUq + i (the shift is in the base)
-      const uint32_t bitp = (P >> (p - 1)) & 1u;
-      if (bitp) { my_lo = nU; my_n = len - nU; }
-      else { my_lo = 0; my_n = nU; }
-      fl = fl && !(DIAG && (dm.dbg & 2));
+    if (DIAG) {
+      if (b <= p - 1) fl = fl && !((dm.dbg & 1) || b <= (dm.dbg >> 8));      // dbg >> 8 = m: prefix bonds 1..m left to another pass (two-pass probe)
+      else if (b == p) fl = fl && !(dm.dbg & 2);
     }
     fmask = __ballot(fl);
   }
-
+  // bit p of P up:   our rows with first suffix site down (i >= nU) <-> partner rows i - nU
+  // bit p of P down: our rows with first suffix site up   (i <  nU) <-> partner rows nUq + i (the shift is in the base)
+  const int st_lo = bitp ? nU : 0, st_n = bitp ? len - nU : nU;
   auto get_bond = [&](int ln) {
     FarBond fb;
-    fb.base = rl64(my_base, ln); fb.J = rld(my_J, ln);
-    fb.lo = rl(my_lo, ln); fb.n = rl(my_n, ln);
+    fb.base = rl64(my_base, ln); fb.J = dm.hop_J[ln];
+    const bool st = ln == p - 1;
+    fb.lo = st ? st_lo : 0; fb.n = st ? st_n : len;
     return fb;
   };
   // rows outside [lo, lo+n) wrap to a huge unsigned offset or exceed n*ES: the load returns 0 and J*0 leaves acc unchanged
-  // Row groups of this wave that lie wholly beyond the tile's last row (a 792-row tile in a 4 x 256 geometry leaves the waves
-  // 1..3 of the last group without a row) issue no far-bond loads at all: their stream registers stay zero.  The range check
-  // would return zeros for them anyway, but every such load still costs the address unit its cycles (TA busy 70 % of the
-  // launch, ablation_r03.md section 5): 19 % of the stream loads of a 792-row tile, 6 % of a 924-row tile.
-  // Float64 only: measured -2...3 % there (L=30 1.640 -> 1.609 ms, L=32 6.89 -> 6.67), but +5 % for ComplexF64 (11.24 -> 11.87 ms).
+  // Row groups of this wave that lie wholly beyond the tile's last row issue no far-bond loads at all: their stream registers
+  // stay zero.  The range check would return zeros for them anyway, but every such load still costs the address unit its
+  // cycles (TA busy 70 % of the launch, ablation_r03.md section 5).
+  // Float64 only: measured -2...3 % there, but +5 % for ComplexF64 (round 3).
   constexpr bool SKIP_DEAD = SD_SKIP_DEAD_ROWS && NC == 1;
   uint32_t live = 0;
   if (SKIP_DEAD) {
 #pragma unroll
     for (int r = 0; r < R; ++r)
-      if (r * BLOCK + (tid & ~63) < len) live |= 1u << r;
+      if ((tid & ~63) / 64 * WR + r * 64 < len) live |= 1u << r;
     live = (uint32_t)__builtin_amdgcn_readfirstlane((int)live);
   }
   auto issue = [&](const FarBond &fb, V(&v)[R]) {
@@ -173,7 +193,7 @@ __global__ __launch_bounds__(BLOCK, (NC == 2 ? SD_LB_C128 : SD_LB_F64)) void k_a
     const uint32_t rel = off0 - (uint32_t)fb.lo * ES;      // wraps for rows below the window: the range check returns 0
 #pragma unroll
     for (int r = 0; r < R; ++r)
-      if (!SKIP_DEAD || ((live >> r) & 1u)) buf_load(v[r], rs, rel + (uint32_t)(r * BLOCK) * ES);
+      if (!SKIP_DEAD || ((live >> r) & 1u)) buf_load(v[r], rs, rel + (uint32_t)(r * 64) * ES);
   };
 
   SD_STAMP(1);
@@ -195,9 +215,19 @@ __global__ __launch_bounds__(BLOCK, (NC == 2 ? SD_LB_C128 : SD_LB_F64)) void k_a
     double dd[R];
     const __amdgpu_buffer_rsrc_t rd = make_rsrc(dm.diag_cache + base, (uint32_t)len * (uint32_t)sizeof(double));
 #pragma unroll
-    for (int r = 0; r < R; ++r) buf_load(dd[r], rd, (uint32_t)(tid + r * BLOCK) * (uint32_t)sizeof(double));
+    for (int r = 0; r < R; ++r) buf_load(dd[r], rd, (uint32_t)i0 * (uint32_t)sizeof(double) + (uint32_t)(r * 64) * (uint32_t)sizeof(double));
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[r] = vscale(dd[r], own[r]);
+  } else if (!need_sig) {
+    // uniform chain zz, exact partial sums (diag_mode 1; diag_of's q * (n_zz - 2 anti)): anti-parallel pairs inside the prefix
+    // (once per thread) + the pair across the prefix | suffix cut + those inside the suffix (4 bits of the packed table)
+    const int antiP = p >= 2 ? __popc((P ^ (P >> 1)) & ((1u << (p - 1)) - 1u)) : 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      int anti = antiP + (int)(dg[r] & 15u) + (p >= 1 ? (int)(bitp ^ (dg[r] >> 4)) : 0);
+      if (dm.n_zz_nn == 0) anti = 0;
+      acc[r] = vscale(dm.diag_q * (double)(dm.n_zz - 2 * anti), own[r]);
+    }
   } else if (dm.diag_mode == 0) {     // no cache (SD_DIAG_CACHE=0 or no memory): the prefix part of the list-order sum once per thread, the rest per row
     const DiagHead dh = diag_head(dm, P, p);
 #pragma unroll
@@ -214,15 +244,16 @@ __global__ __launch_bounds__(BLOCK, (NC == 2 ? SD_LB_C128 : SD_LB_F64)) void k_a
   }
 #pragma unroll
   for (int r = 0; r < R; ++r)
-    if (tid + r * BLOCK < len) tile[tid + r * BLOCK] = own[r];
-  if (tid == 0) tile[max_len] = V{};   // the zero row read by lanes whose suffix bond is not flippable
-  for (int k = tid; k < 16 * SD_BIN_STRIDE; k += BLOCK) {
-    int n = k / SD_BIN_STRIDE, kk = k - n * SD_BIN_STRIDE;
-    lbin[k] = (int)binom_g(dm, n, kk);
-  }
+    if (i0 + r * 64 < len) tile[1 + i0 + r * 64] = own[r];
+  if (tid == 0) tile[0] = V{};         // the zero row read by lanes whose suffix bond is not flippable
+  if (!PK)
+    for (int k = tid; k < 16 * SD_BIN_STRIDE; k += BLOCK) {
+      int n = k / SD_BIN_STRIDE, kk = k - n * SD_BIN_STRIDE;
+      lbin[k] = (int)binom_g(dm, n, kk);
+    }
 
   SD_STAMP(2);
-  // The only barrier: own rows and binomials are in LDS.  Placed BEFORE the far-bond streams (all waves are at the same
+  // The only barrier: own rows (and binomials) are in LDS.  Placed BEFORE the far-bond streams (all waves are at the same
   // point here, their own rows have just arrived), so that afterwards every wave runs its stream and suffix phases on
   // its own clock and one wave's LDS/VALU phase overlaps its neighbours' memory phase.
   __syncthreads();
@@ -230,6 +261,17 @@ __global__ __launch_bounds__(BLOCK, (NC == 2 ? SD_LB_C128 : SD_LB_F64)) void k_a
   // (The issues are conditional, so the compiler cannot count the loads in flight and drains them all before each
   // accumulation: the two register sets overlap less than the source suggests.  Three rewrites with counted waits -- loads
   // always issued, EMPTY bonds at the end -- were measured and lose or tie: profiles/ablation_r03.md section 3.)
+#if SD_FAR_DEPTH == 1
+  // one register set: a wave waits for each bond's rows before it asks for the next; the overlap comes from the other waves
+  // of the SIMD (the registers saved buy two more of them)
+  while (have_a) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = accum<FMA>(acc[r], fa.J, va[r]);
+    have_a = false;
+    if (mk) { fa = get_bond(next_lane(mk)); issue(fa, va); have_a = true; }
+  }
+  (void)fbb; (void)vb;
+#else
   while (have_a) {
     bool have_b = false;
     if (mk) { fbb = get_bond(next_lane(mk)); issue(fbb, vb); have_b = true; }
@@ -241,7 +283,15 @@ __global__ __launch_bounds__(BLOCK, (NC == 2 ? SD_LB_C128 : SD_LB_F64)) void k_a
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[r] = accum<FMA>(acc[r], fbb.J, vb[r]);
   }
+#endif
   SD_STAMP(3);
+  // The packed partner table of the suffix bonds is requested only now: its 4 registers per row would otherwise be live
+  // across the stream phase and cost a wave per SIMD (89 instead of 74 VGPRs for ComplexF64).  An L2 / L1 hit.
+  if (PK && nn > 0) {
+    const __amdgpu_buffer_rsrc_t rp = make_rsrc(dm.suf_part + 4 * (size_t)rec.suf_off, (uint32_t)len * 16u);
+#pragma unroll
+    for (int r = 0; r < R; ++r) pt[PK ? r : 0] = __builtin_amdgcn_raw_buffer_load_b128(rp, (uint32_t)i0 * 16u + (uint32_t)(r * 64) * 16u, 0, 0);
+  }
   SD_STAMP(4);
 
   // ---- general bonds (anything after the leading chain bonds: the periodic (L,1) bond, long-range lists) ----
@@ -276,8 +326,8 @@ __global__ __launch_bounds__(BLOCK, (NC == 2 ? SD_LB_C128 : SD_LB_F64)) void k_a
     return false;
   };
   auto gvalue = [&](const GBond &g, int r) -> V {         // psi at the partner row of row r (call only when gflip)
-    if (g.kind == 1) return tile[dm.suf_rank[sig[r] ^ g.smask]];
-    const int64_t idx = g.base + (g.kind == 0 ? (int64_t)(tid + r * BLOCK) : (int64_t)dm.suf_rank[sig[r] ^ g.smask]);
+    if (g.kind == 1) return tile[1 + dm.suf_rank[sig[r] ^ g.smask]];
+    const int64_t idx = g.base + (g.kind == 0 ? (int64_t)(i0 + r * 64) : (int64_t)dm.suf_rank[sig[r] ^ g.smask]);
     return (halo && idx >= dm.n_local) ? halo[idx - dm.n_local] : psi[idx];
   };
   // the first general bond's values are requested now, into the idle stream registers, so that their latency hides behind
@@ -285,45 +335,63 @@ __global__ __launch_bounds__(BLOCK, (NC == 2 ? SD_LB_C128 : SD_LB_F64)) void k_a
   const bool have_g = nn < dm.n_hop;
   double gJ = 0.0;
   GBond g0{0, 0u, 0, -1};
-  if (have_g) {
+  auto request_g0 = [&]() {
     g0 = gbond(nn);
     gJ = dm.hop_J[nn];
 #pragma unroll
-    for (int r = 0; r < R; ++r) va[r] = (tid + r * BLOCK < len && gflip(g0, r)) ? gvalue(g0, r) : V{};
-  }
-  // ---- 4. bonds inside the suffix: LDS reads at idx +- C(LS-a-1, u); branch-free so the R rows' reads overlap ----
+    for (int r = 0; r < R; ++r) va[r] = (i0 + r * 64 < len && gflip(g0, r)) ? gvalue(g0, r) : V{};
+  };
+  // (PK: requested after the suffix phase instead -- values held across it would sit on top of the packed table's registers
+  // and cost every model, with or without general bonds, a wave per SIMD)
+  if (have_g && !PK) request_g0();
+  // ---- 4. bonds inside the suffix ----
   if (nn > 0 && !(DIAG && (dm.dbg & 4))) {
-    uint32_t dw[R];   // bit a-1 set <=> suffix bond a is flippable
+    if constexpr (PK) {
+      // partner row + 1 from the packed table (0: no hop -> the zero row); branch-free, the R rows' LDS reads overlap
+      const unsigned char *tb = reinterpret_cast<const unsigned char *>(tile);
+      constexpr uint32_t SH = NC == 2 ? 4 : 3;            // log2(sizeof(V))
 #pragma unroll
-    for (int r = 0; r < R; ++r) dw[r] = sig[r] ^ (sig[r] >> 1);
-    // RL = row groups the loop covers (all R)
-    auto suffix_phase = [&](auto RLc) {
-      constexpr int RL = decltype(RLc)::value;
+      for (int a = 1; a <= 11; ++a) if (a <= LS - 1) {     // wave-uniform guard (LS is a run-time value <= 12)
+        const double J = dm.hop_J[p + a - 1];
+        const int w = (a - 1) / 3, sh = 10 * ((a - 1) % 3);
+        V v[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const u4 q = pt[PK ? r : 0];
+          const uint32_t word = w == 0 ? q.x : w == 1 ? q.y : w == 2 ? q.z : q.w;
+          const uint32_t ad = ((word >> sh) & 0x3FFu) << SH;
+          v[r] = *reinterpret_cast<const V *>(tb + ad);
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = accum<FMA>(acc[r], J, v[r]);
+      }
+    } else {
+      // LS > 12: LDS reads at idx +- C(LS-a-1, u), u = ups beyond the bond (binomials in LDS)
+      uint32_t dw[R];   // bit a-1 set <=> suffix bond a is flippable
+#pragma unroll
+      for (int r = 0; r < R; ++r) dw[r] = sig[r] ^ (sig[r] >> 1);
       for (int a = 1; a <= LS - 1; ++a) {
         const double J = dm.hop_J[p + a - 1];
         const int *brow = lbin + (LS - a - 1) * SD_BIN_STRIDE;
-        int d[RL];
+        int d[R];
 #pragma unroll
-        for (int r = 0; r < RL; ++r) d[r] = brow[__popc(sig[r] >> (a + 1))];
-        V v[RL];
+        for (int r = 0; r < R; ++r) d[r] = brow[__popc(sig[r] >> (a + 1))];
+        V v[R];
 #pragma unroll
-        for (int r = 0; r < RL; ++r) {
+        for (int r = 0; r < R; ++r) {
           const bool up = (sig[r] >> (a - 1)) & 1u;
           const bool fl = (dw[r] >> (a - 1)) & 1u;
-          const int ip = (tid + r * BLOCK) + (up ? d[r] : -d[r]);
-          v[r] = tile[fl ? ip : max_len];
+          const int ip = (i0 + r * 64) + (up ? d[r] : -d[r]);
+          v[r] = tile[fl ? ip + 1 : 0];
         }
 #pragma unroll
-        for (int r = 0; r < RL; ++r) acc[r] = accum<FMA>(acc[r], J, v[r]);
+        for (int r = 0; r < R; ++r) acc[r] = accum<FMA>(acc[r], J, v[r]);
       }
-    };
-    // (Float64, dispatching on the number of live row groups -- R, R-1, R-2 -- so that dead groups skip the phase: 99 VGPRs
-    // instead of 94, a wave per SIMD lost, 1.605 -> 1.67 ms at L=30; with launch bounds for 5 waves 12 B of scratch and 1.66 ms.
-    // Not used.  The loop as a lambda alone moves ComplexF64 from 76 to 74 VGPRs and 11.24 -> 11.09 ms at L=32.)
-    suffix_phase(std::integral_constant<int, R>{});
+    }
   }
   // ---- the general bonds in list order ----
   if (have_g) {
+    if (PK) request_g0();
 #pragma unroll
     for (int r = 0; r < R; ++r)
       if (gflip(g0, r)) acc[r] = accum<false>(acc[r], gJ, va[r]);   // rows without the hop keep acc untouched
@@ -333,7 +401,7 @@ __global__ __launch_bounds__(BLOCK, (NC == 2 ? SD_LB_C128 : SD_LB_F64)) void k_a
       const double J = dm.hop_J[h];
 #pragma unroll
       for (int r = 0; r < R; ++r)
-        if (tid + r * BLOCK < len && gflip(g, r)) acc[r] = accum<false>(acc[r], J, gvalue(g, r));
+        if (i0 + r * 64 < len && gflip(g, r)) acc[r] = accum<false>(acc[r], J, gvalue(g, r));
     }
   }
 
@@ -342,8 +410,8 @@ __global__ __launch_bounds__(BLOCK, (NC == 2 ? SD_LB_C128 : SD_LB_F64)) void k_a
   EpiSums sums{0.0, 0.0};
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    const int i = tid + r * BLOCK;
-    if (i < len) epilogue<NC>(epi, ea, base + i, acc[r], tile[i], out_, sums);
+    const int i = i0 + r * 64;
+    if (i < len) epilogue<NC>(epi, ea, base + i, acc[r], tile[1 + i], out_, sums);
   }
   SD_STAMP(6);
   if (DIAG && stamp && tid == 0) stamp[7] = __builtin_amdgcn_s_memrealtime();
@@ -631,14 +699,14 @@ int sd_launch_epilogue_only(sd_ctx *ctx, int dtype, int64_t n, void *out, const 
 }
 namespace {
 
-template <int NC, int R, int BLOCK, bool FMA>
+template <int NC, int R, int BLOCK, bool FMA, bool PK>
 int launch_tiled_cfg(sd_ctx *ctx, const sd_dev_model &dm, int nt, size_t shmem, double *out, const double *psi, int epi,
                      const sd_epi_args &ea, int max_len) {
   // the stamped (DIAG) instantiation exists for one configuration only and is reached through sd_debug_phase_profile
-  void (*kern)(sd_dev_model, double *, const double *, int, sd_epi_args, double *, int) = k_apply_tiled<NC, R, BLOCK, FMA>;
+  void (*kern)(sd_dev_model, double *, const double *, int, sd_epi_args, double *, int) = k_apply_tiled<NC, R, BLOCK, FMA, PK>;
   // ... and for the SD_DEBUG_SKIP timing ablations: the production instantiations carry no run-time debug branches
-  if constexpr (NC == 2 && FMA && (BLOCK == 256 || BLOCK == 128 || BLOCK == 64))
-    if (dm.stamps || dm.dbg) kern = k_apply_tiled<NC, R, BLOCK, FMA, true>;
+  if constexpr (NC == 2 && FMA && PK && (BLOCK == 256 || BLOCK == 128 || BLOCK == 64))
+    if (dm.stamps || dm.dbg) kern = k_apply_tiled<NC, R, BLOCK, FMA, PK, true>;
   // per kernel AND per device, so no cache: cheap next to a launch, and only the SD_SUFFIX_BITS >= 13 tiles get here
   if (shmem > 48 * 1024)
     SD_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
@@ -653,23 +721,29 @@ int launch_tiled(sd_ctx *ctx, const sd_dev_model &dm, int nt, int cls, size_t sh
   // 4 rows per thread; cls selects the workgroup size (64 << cls threads) that covers the segment's longest tile
   constexpr int R = 4;
   if ((64 << cls) * R < max_len) return sd_set_err(ctx, SD_EINTERNAL, "tile longer than its workgroup can hold");
+  if (!dm.suf_part) {
+    // LS > 12 (SD_SUFFIX_BITS experiments): partners from binomials, the two largest workgroups only (basis.cpp puts every
+    // tile of such a plan into one class >= 3)
+    switch (cls) {
+      case 3: return launch_tiled_cfg<NC, R, 512, FMA, false>(ctx, dm, nt, shmem, out, psi, epi, ea, max_len);
+      case 4: return launch_tiled_cfg<NC, R, 1024, FMA, false>(ctx, dm, nt, shmem, out, psi, epi, ea, max_len);
+    }
+    return sd_set_err(ctx, SD_EINTERNAL, "bad tile length class for a plan without the packed partner table");
+  }
   if constexpr (NC == 1) {
     // Float64: 8 rows per thread in workgroups of half the size (same registers as 4 ComplexF64 rows; the per-thread
     // set-up -- far-bond list, descriptors -- is paid once per 8 rows).  SD_F64_ROWS=4 keeps 4 rows per thread.
     static const int rows = getenv("SD_F64_ROWS") ? atoi(getenv("SD_F64_ROWS")) : 8;   // measured at L=30: 1.80 -> 1.74 ms
-    if (rows == 8 && cls >= 1 && cls <= 3)
+    if (rows == 8 && cls >= 1 && cls <= 2)
       switch (cls) {
-        case 1: return launch_tiled_cfg<NC, 8, 64, FMA>(ctx, dm, nt, shmem, out, psi, epi, ea, max_len);
-        case 2: return launch_tiled_cfg<NC, 8, 128, FMA>(ctx, dm, nt, shmem, out, psi, epi, ea, max_len);
-        case 3: return launch_tiled_cfg<NC, 8, 256, FMA>(ctx, dm, nt, shmem, out, psi, epi, ea, max_len);
+        case 1: return launch_tiled_cfg<NC, 8, 64, FMA, true>(ctx, dm, nt, shmem, out, psi, epi, ea, max_len);
+        case 2: return launch_tiled_cfg<NC, 8, 128, FMA, true>(ctx, dm, nt, shmem, out, psi, epi, ea, max_len);
       }
   }
-  switch (cls) {
-    case 0: return launch_tiled_cfg<NC, R, 64, FMA>(ctx, dm, nt, shmem, out, psi, epi, ea, max_len);
-    case 1: return launch_tiled_cfg<NC, R, 128, FMA>(ctx, dm, nt, shmem, out, psi, epi, ea, max_len);
-    case 2: return launch_tiled_cfg<NC, R, 256, FMA>(ctx, dm, nt, shmem, out, psi, epi, ea, max_len);
-    case 3: return launch_tiled_cfg<NC, R, 512, FMA>(ctx, dm, nt, shmem, out, psi, epi, ea, max_len);
-    case 4: return launch_tiled_cfg<NC, R, 1024, FMA>(ctx, dm, nt, shmem, out, psi, epi, ea, max_len);
+  switch (cls) {      // LS <= 12: at most C(12,6) = 924 rows, i.e. class 2
+    case 0: return launch_tiled_cfg<NC, R, 64, FMA, true>(ctx, dm, nt, shmem, out, psi, epi, ea, max_len);
+    case 1: return launch_tiled_cfg<NC, R, 128, FMA, true>(ctx, dm, nt, shmem, out, psi, epi, ea, max_len);
+    case 2: return launch_tiled_cfg<NC, R, 256, FMA, true>(ctx, dm, nt, shmem, out, psi, epi, ea, max_len);
   }
   return sd_set_err(ctx, SD_EINTERNAL, "bad tile length class");
 }

@@ -112,6 +112,14 @@ struct sd_dev_model {
   const uint16_t *suf_states;    // concatenated sectors (LS, t'), t' = 0..LS
   const int32_t *suf_off;        // LS+2 offsets into suf_states
   const uint16_t *suf_rank;      // 2^LS entries: rank of sigma inside its sector
+  // Packed partner table of the suffix bonds (LS <= 12), one 16-byte entry per row of every suffix sector, indexed like
+  // suf_states: word w holds three 10-bit fields, field 3*w + j (bits 10j..10j+9) = 1 + (row of the hop partner on suffix bond
+  // a = 3*w + j + 1 inside the tile), 0 when the bond cannot flip.  Word 3 also carries, above its two bond fields, the number of
+  // anti-parallel neighbour pairs INSIDE the suffix (bits 20..23) and the first suffix site (bit 30): with them the uniform-zz
+  // diagonal needs no configuration at all.  Null for LS > 12 (k_apply_tiled then computes partners from binomials).
+  const uint32_t *suf_part;
+  const uint8_t *suf_dg;         // per row of every suffix sector: anti-parallel pairs inside the suffix (bits 0..3), first suffix site (bit 4); with suf_part
+  int need_sig;                  // the kernel must load the rows' suffix configurations (general bonds, or a diagonal that is not the uniform chain form / cached)
   const int64_t *far_base;       // per processed tile (single_rec order) p entries: base of the partner tile for prefix bond b = lane+1 and, in entry p-1, of the straddling bond's partner rows; -1: no hop
   int n_singles;
   int n_interior;                // sharded plans: the first n_interior single tiles read no halo (their partners are all owned)
@@ -144,6 +152,8 @@ struct sd_model {
   std::vector<int64_t> tile_base;
   std::vector<int64_t> addr;
   std::vector<uint16_t> suf_states, suf_rank;
+  std::vector<uint32_t> suf_part;   // packed suffix-bond partner table (see sd_dev_model), empty for LS > 12
+  std::vector<uint8_t> suf_dg;
   std::vector<int64_t> far_base;
   std::vector<int32_t> suf_off;
   std::vector<sd_slab> recv_slabs, send_slabs;
