@@ -27,6 +27,13 @@ t0 = time.time()
 S = sd.dynamical_structure_factor(model, psi0, q, omega, method="kpm", kpm_m=80, kernel="jackson")
 dt = time.time() - t0
 print("dynamical_structure_factor(:kpm, kpm_m=80): %.3f s for %d momenta x %d frequencies" % (dt, len(q), len(omega)))
+# the same call with one momentum at a time (what the recursion looked like before the momenta shared their launches)
+model.ctx.set_q_batch(False)
+t0 = time.time()
+S1 = sd.dynamical_structure_factor(model, psi0, q, omega, method="kpm", kpm_m=80, kernel="jackson")
+dt1 = time.time() - t0
+model.ctx.set_q_batch(True)
+print("  one momentum at a time: %.3f s (x%.1f); max |S - S_one_at_a_time| = %.1e" % (dt1, dt1 / dt, np.abs(S - S1).max()))
 iq = L // 2
 print("S(pi, w) peaks at w = %.3f with %.5f;  sum over w of S(pi, w) dw = %.5f" % (
     omega[np.argmax(S[iq])], S[iq].max(), S[iq].sum() * (omega[1] - omega[0])))

@@ -81,6 +81,11 @@ int sd_ctx_set_kpm_doubling(sd_ctx *ctx, int on);
  * q on its own, as the reference does (src/KPM_Sqw.jl:218-252, src/LanczosSqw.jl:63-77).  The copied row differs from a recomputed one by the rounding of exp(iqr) only (<= 1e-13
  * on S).  Never used with a caller's operator (sd_ctx_set_apply_callback). */
 int sd_ctx_set_kpm_pair_q(sd_ctx *ctx, int on);
+/* sd_kpm_sqw / sd_lanczos_sqw on one GPU: the reference threads over the momenta (src/KPM_Sqw.jl:218, src/LanczosSqw.jl:65).  on != 0
+ * (default; env SD_Q_BATCH=0 changes the default) lets the momenta's vectors share every launch of the recursion where a single
+ * vector cannot fill the chip (vectors of at most 2^22 rows, tiled plans): one batched apply per step for all momenta.  Each
+ * momentum sees exactly the arithmetic of a recursion of its own -- S(q, w) is bit-identical; on == 0: one momentum at a time. */
+int sd_ctx_set_q_batch(sd_ctx *ctx, int on);
 /* sd_lanczos_groundstate re-orthogonalises H v_j against v_1 .. v_{j-1} (src/Lanczos.jl:116-124).  on != 0 (default): in blocks
  * of 8 columns -- the coefficients of a block are its dots with w as it stands when the block begins (classical Gram-Schmidt
  * inside a block, modified between blocks), one pass over w per block instead of per column.  With v_k orthonormal to rounding

@@ -63,6 +63,9 @@ set_kpm_doubling!(ctx::Context, on::Bool) =
 # real psi0: S(q, w) once per pair (q, 2pi - q) (default) or every q on its own as src/KPM_Sqw.jl:218-252 does
 set_kpm_pair_q!(ctx::Context, on::Bool) =
     check(ccall((:sd_ctx_set_kpm_pair_q, libspindyn), Cint, (Ptr{Cvoid}, Cint), ctx.h, on ? 1 : 0), ctx.h)
+# S(q, w): the momenta's vectors share the launches of their recursions at launch-bound sizes (default), or one momentum at a time
+set_q_batch!(ctx::Context, on::Bool) =
+    check(ccall((:sd_ctx_set_q_batch, libspindyn), Cint, (Ptr{Cvoid}, Cint), ctx.h, on ? 1 : 0), ctx.h)
 # groundstate: full re-orthogonalisation in blocks of 8 columns (default) or column by column as src/Lanczos.jl:116-124
 set_gs_blocked!(ctx::Context, on::Bool) =
     check(ccall((:sd_ctx_set_gs_blocked, libspindyn), Cint, (Ptr{Cvoid}, Cint), ctx.h, on ? 1 : 0), ctx.h)

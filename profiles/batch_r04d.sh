@@ -1,0 +1,10 @@
+#!/bin/bash
+set -u
+export TMPDIR=/tmp
+OUT=$PWD/gpurun_out/r04d
+mkdir -p $OUT
+python -m pytest tests -x -q -m gpu > $OUT/pytest.log 2>&1; echo "pytest rc=$?" | tee -a $OUT/pytest.log; tail -8 $OUT/pytest.log
+python profiles/smallL_bench.py > $OUT/smallL.jsonl 2>&1; cat $OUT/smallL.jsonl
+SD_FLAT=0 python profiles/smallL_bench.py 2>&1 | grep lanczos_tridiag | sed 's/^/NOFLAT /' | tee -a $OUT/smallL.jsonl
+python profiles/smallL_sqw_bench.py > $OUT/smallL_sqw.jsonl 2>&1; cat $OUT/smallL_sqw.jsonl
+python examples/kpm_sqw.py 2>&1 | tee $OUT/example_kpm_sqw.txt

@@ -86,6 +86,7 @@ PROTOTYPES = {
     "sd_ctx_set_stream": (_i, [_vp, _vp]),
     "sd_ctx_set_kpm_doubling": (_i, [_vp, _i]),
     "sd_ctx_set_kpm_pair_q": (_i, [_vp, _i]),
+    "sd_ctx_set_q_batch": (_i, [_vp, _i]),
     "sd_ctx_set_gs_blocked": (_i, [_vp, _i]),
     "sd_ctx_apply_count": (_i64, [_vp]),
     "sd_ctx_release_scratch": (_i, [_vp]),
@@ -229,6 +230,11 @@ class Context:
         """True (default): kpm_sqw of a real psi0 computes each pair of momenta (q, 2 pi - q) once; False: every q on its own,
         as the reference does."""
         check(lib().sd_ctx_set_kpm_pair_q(self.h, 1 if on else 0), self.h)
+
+    def set_q_batch(self, on):
+        """True (default): the momenta of kpm_sqw / lanczos_sqw share the launches of their recursions at launch-bound sizes
+        (bit-identical S); False: one momentum at a time."""
+        check(lib().sd_ctx_set_q_batch(self.h, 1 if on else 0), self.h)
 
     def set_gs_blocked(self, on):
         """True (default): lanczos_groundstate re-orthogonalises in blocks of 8 columns; False: column by column (reference order)."""

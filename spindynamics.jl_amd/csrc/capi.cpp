@@ -174,6 +174,7 @@ int sd_ctx_create(int device, sd_ctx **out) {
     return fail(nullptr, SD_EHIP, "context allocation failed");
   }
   (void)hipMemset(c->d_scalars, 0, 16 * sizeof(double));
+  if (const char *e = getenv("SD_Q_BATCH")) c->q_batch = atoi(e) ? 1 : 0;
   *out = c;
   return SD_OK;
 }
@@ -217,6 +218,12 @@ int sd_ctx_set_gs_blocked(sd_ctx *ctx, int on) {
 int sd_ctx_set_kpm_pair_q(sd_ctx *ctx, int on) {
   if (!ctx) return SD_EARG;
   ctx->kpm_pair_q = on ? 1 : 0;
+  return SD_OK;
+}
+
+int sd_ctx_set_q_batch(sd_ctx *ctx, int on) {
+  if (!ctx) return SD_EARG;
+  ctx->q_batch = on ? 1 : 0;
   return SD_OK;
 }
 

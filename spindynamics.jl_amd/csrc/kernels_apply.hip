@@ -92,6 +92,14 @@ __global__ __launch_bounds__(BLOCK, (NC == 2 ? SD_LB_C128 : SD_LB_F64)) void k_a
   int *lbin = reinterpret_cast<int *>(smem + (size_t)(max_len + 1) * sizeof(V));   // !PK only
   double *red = reinterpret_cast<double *>(lbin + 16 * SD_BIN_STRIDE);
 
+  if (ea.batch > 1) {                                          // vector blockIdx.y of a batch (sd_epi_args::batch)
+    const int64_t boff = (int64_t)blockIdx.y * ea.bstride * NC;      // in doubles
+    psi_ += boff; out_ += boff;
+    if (ea.prev) ea.prev = (const double *)ea.prev + boff;
+    if (ea.phi) ea.phi = (const double *)ea.phi + boff;
+    if (ea.accv) ea.accv = (double *)ea.accv + boff;
+    partials += 2 * (size_t)blockIdx.y * (size_t)dm.n_singles;
+  }
   const V *__restrict__ psi = reinterpret_cast<const V *>(psi_);
   const V *__restrict__ halo = reinterpret_cast<const V *>(ea.halo);
   const int tid = threadIdx.x;
@@ -637,10 +645,12 @@ __global__ __launch_bounds__(256) void k_epilogue_only(int epi, sd_epi_args ea, 
   }
 }
 
-// fixed-order reduction of the per-block partial pairs -> scalars[0..1]
+// fixed-order reduction of the per-block partial pairs -> scalars[0..1]; block k of a batched call reduces list k
 __global__ __launch_bounds__(1024) void k_reduce_pairs(const double *__restrict__ partials, int64_t n,
-                                                       double *__restrict__ scalars) {
+                                                       double *__restrict__ scalars, int64_t dstride) {
   __shared__ double red[32];
+  partials += 2 * (size_t)blockIdx.x * (size_t)n;
+  scalars += (size_t)blockIdx.x * (size_t)dstride;
   double a = 0.0, b = 0.0;
   for (int64_t i = threadIdx.x; i < n; i += blockDim.x) { a += partials[2 * i]; b += partials[2 * i + 1]; }
   block_reduce2(a, b, red);
@@ -672,7 +682,13 @@ int sd_reduce_pairs(sd_ctx *ctx, int64_t n, double *dst) {
     SD_HIP(ctx, hipGetLastError());
     src = stage; n = SD_RED_STAGE_BLOCKS;
   }
-  hipLaunchKernelGGL(k_reduce_pairs, dim3(1), dim3(1024), 0, ctx->stream, src, n, dst);
+  hipLaunchKernelGGL(k_reduce_pairs, dim3(1), dim3(1024), 0, ctx->stream, src, n, dst, (int64_t)0);
+  SD_HIP(ctx, hipGetLastError());
+  return SD_OK;
+}
+int sd_reduce_pairs_batched(sd_ctx *ctx, int64_t n, int batch, double *dst, int64_t dstride) {
+  if (!dst || n > 16384 || batch < 1) return sd_set_err(ctx, SD_EINTERNAL, "bad batched reduction");
+  hipLaunchKernelGGL(k_reduce_pairs, dim3((unsigned)batch), dim3(1024), 0, ctx->stream, ctx->d_partials, n, dst, dstride);   // same geometry as one list alone: same bits
   SD_HIP(ctx, hipGetLastError());
   return SD_OK;
 }
@@ -710,7 +726,7 @@ int launch_tiled_cfg(sd_ctx *ctx, const sd_dev_model &dm, int nt, size_t shmem, 
   // per kernel AND per device, so no cache: cheap next to a launch, and only the SD_SUFFIX_BITS >= 13 tiles get here
   if (shmem > 48 * 1024)
     SD_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-  hipLaunchKernelGGL(kern, dim3(nt), dim3(BLOCK), shmem, ctx->stream, dm, out, psi, epi, ea, ctx->d_partials, max_len);
+  hipLaunchKernelGGL(kern, dim3(nt, ea.batch > 1 ? ea.batch : 1), dim3(BLOCK), shmem, ctx->stream, dm, out, psi, epi, ea, ctx->d_partials, max_len);
   SD_HIP(ctx, hipGetLastError());
   return SD_OK;
 }
@@ -765,6 +781,9 @@ int sd_launch_apply(sd_ctx *ctx, const sd_model *m, int dtype, void *out, const 
     if (sums) SD_HIP(ctx, hipMemsetAsync(ea.sums_dst ? ea.sums_dst : ctx->d_scalars, 0, 2 * sizeof(double), ctx->stream));
     return SD_OK;
   }
+  if (ea.no_reduce && (m->p < 0 || part != 0)) return sd_set_err(ctx, SD_EINTERNAL, "unreduced sums: whole tiled plans only");
+  if (ea.batch > 1 && (m->p < 0 || m->nranks != 1 || part != 0 || dm.n_singles > 16384 || (sums && !ea.sums_dst && !ea.no_reduce)))
+    return sd_set_err(ctx, SD_EINTERNAL, "batched apply: unsharded tiled plans with at most 16384 tiles only");
   if (m->p >= 0) {
     // part 0: every tile; 1: interior tiles only (no halo read); 2: boundary tiles only.  A sum epilogue run in two parts
     // (1, then 2 with the same epilogue) files its per-tile partial sums into disjoint slots of one buffer and reduces
@@ -772,7 +791,7 @@ int sd_launch_apply(sd_ctx *ctx, const sd_model *m, int dtype, void *out, const 
     int nt = dm.n_singles;
     if (part == 1) nt = dm.n_interior;
     else if (part == 2) nt = dm.n_singles - dm.n_interior;
-    if (sums) { int rc = sd_ensure_partials(ctx, 2 * (size_t)dm.n_singles + 2 * SD_RED_STAGE_BLOCKS); if (rc) return rc; }
+    if (sums) { int rc = sd_ensure_partials(ctx, 2 * (size_t)dm.n_singles * (size_t)std::max(ea.batch, 1) + 2 * SD_RED_STAGE_BLOCKS); if (rc) return rc; }
     const int max_len = m->max_tile_len;
     const size_t esz = dtype == SD_C128 ? 16 : 8;
     int rc = SD_OK;
@@ -804,8 +823,9 @@ int sd_launch_apply(sd_ctx *ctx, const sd_model *m, int dtype, void *out, const 
       }
       if (rc) return rc;
     }
-    if (sums && part != 1) {
-      int rc2 = sd_reduce_pairs(ctx, (int64_t)dm.n_singles, ea.sums_dst);
+    if (sums && part != 1 && !ea.no_reduce) {
+      int rc2 = ea.batch > 1 ? sd_reduce_pairs_batched(ctx, (int64_t)dm.n_singles, ea.batch, ea.sums_dst, ea.sums_bstride)
+                             : sd_reduce_pairs(ctx, (int64_t)dm.n_singles, ea.sums_dst);
       if (rc2) return rc2;
     }
   } else if (m->full_ls > 0) {

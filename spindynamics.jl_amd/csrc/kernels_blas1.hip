@@ -309,6 +309,73 @@ __global__ __launch_bounds__(BS) void k_lanczos_fold(double2 *__restrict__ t, co
   block_reduce2(s, s1, red);
   if (threadIdx.x == 0) { partials[2 * blockIdx.x] = s; partials[2 * blockIdx.x + 1] = 0.0; }
 }
+// ---- the same update for launch-bound sizes: the reductions' second stages folded into the consuming pass, batched ----
+// A Lanczos step of a small system is four launches of a few microseconds of host time each (apply + its reduction, update +
+// its reduction): 19-22 us per step whatever the dimension.  Here every block of the update sums the producer's partial lists
+// itself -- the apply's per-tile pairs of <u|t>, the previous updates' per-block |w|^2 -- in one fixed order (so all blocks of a
+// vector agree to the bit), and writes its own |w|^2 partial for the next step: two launches per step.  grid.y = vectors of a
+// batch stored `bstride` elements apart (the momenta of lanczos_sqw, src/LanczosSqw.jl:65), each with its own lists and scalars.
+__device__ __forceinline__ void sum_list(const double *__restrict__ p, int n, double *red, double *bc /* 2 doubles LDS */) {
+  double a = 0.0, b = 0.0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) { a += p[2 * i]; b += p[2 * i + 1]; }
+  __syncthreads();
+  block_reduce2(a, b, red);
+  if (threadIdx.x == 0) { bc[0] = a; bc[1] = b; }
+  __syncthreads();
+}
+template <int FORM, bool HAVE_U>
+__global__ __launch_bounds__(BS) void k_lanczos_fold_p(double2 *__restrict__ t, const double2 *__restrict__ uc,
+                                                       const double2 *__restrict__ up, int64_t N, int64_t bstride,
+                                                       const double *__restrict__ dotp, int ndot,
+                                                       const double *__restrict__ n2cp, const double *__restrict__ n2pp, int nn2,
+                                                       double *__restrict__ store_alpha, double *__restrict__ store_bc,
+                                                       int64_t store_stride, double *__restrict__ n2out) {
+  __shared__ double red[32];
+  __shared__ double sc[6];
+  const int q = blockIdx.y;
+  t += (int64_t)q * bstride; uc += (int64_t)q * bstride;
+  if (HAVE_U) up += (int64_t)q * bstride;
+  sum_list(dotp + 2 * (size_t)ndot * q, ndot, red, sc);
+  if (n2cp) sum_list(n2cp + 2 * (size_t)nn2 * q, nn2, red, sc + 2);
+  if (n2pp) sum_list(n2pp + 2 * (size_t)nn2 * q, nn2, red, sc + 4);
+  const FoldScalars f = fold_resolve(sc, n2cp ? sc + 2 : nullptr, n2pp ? sc + 4 : nullptr, FORM,
+                                     store_alpha ? store_alpha + (int64_t)q * store_stride : nullptr,
+                                     store_bc ? store_bc + (int64_t)q * store_stride : nullptr, blockIdx.x == 0 && threadIdx.x == 0);
+  double s = 0.0, s1 = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += stride) {
+    const double2 tt = t[i], cc = uc[i];
+    const double wx = tt.x / f.bc, wy = tt.y / f.bc, vx = cc.x / f.bc, vy = cc.y / f.bc;
+    double ux = 0.0, uy = 0.0;
+    if (HAVE_U) { const double2 pp = up[i]; ux = pp.x / f.bp; uy = pp.y / f.bp; }
+    double2 r;
+    if (FORM == 0) {
+      r.x = HAVE_U ? wx - (f.ar * vx + f.bc * ux) : wx - f.ar * vx;
+      r.y = HAVE_U ? wy - (f.ar * vy + f.bc * uy) : wy - f.ar * vy;
+    } else {
+      r.x = wx - f.ar * vx; r.y = wy - f.ar * vy;
+      if (HAVE_U) { r.x -= f.bc * ux; r.y -= f.bc * uy; }
+    }
+    t[i] = r;
+    s += r.x * r.x + r.y * r.y;
+  }
+  __syncthreads();
+  block_reduce2(s, s1, red);
+  if (threadIdx.x == 0) { n2out[2 * ((size_t)gridDim.x * q + blockIdx.x)] = s; n2out[2 * ((size_t)gridDim.x * q + blockIdx.x) + 1] = 0.0; }
+}
+// the scalars of the last step (alpha_m and beta_{m-1}) from the partial lists; one block per vector
+__global__ __launch_bounds__(BS) void k_lanczos_fold_scalars_p(const double *__restrict__ dotp, int ndot, const double *__restrict__ n2cp,
+                                                               int nn2, int form, double *store_alpha, double *store_bc,
+                                                               int64_t store_stride) {
+  __shared__ double red[32];
+  __shared__ double sc[4];
+  const int q = blockIdx.x;
+  sum_list(dotp + 2 * (size_t)ndot * q, ndot, red, sc);
+  if (n2cp) sum_list(n2cp + 2 * (size_t)nn2 * q, nn2, red, sc + 2);
+  (void)fold_resolve(sc, n2cp ? sc + 2 : nullptr, nullptr, form, store_alpha + (int64_t)q * store_stride,
+                     store_bc ? store_bc + (int64_t)q * store_stride : nullptr, threadIdx.x == 0);
+}
+
 // the scalars of the last step alone (the recursion ends on alpha_m: no vector update behind it)
 __global__ void k_lanczos_fold_scalars(const double *dot, const double *n2c, int form, double *store_alpha, double *store_bc) {
   (void)fold_resolve(dot, n2c, nullptr, form, store_alpha, store_bc, true);
@@ -386,6 +453,25 @@ int sd_k_dot(sd_ctx *ctx, int nc, const double *x, const double *y, int64_t N, i
   if (nc == 2) hipLaunchKernelGGL(k_dot<2>, dim3(nb), dim3(BS), 0, ctx->stream, x, y, N, ctx->d_partials);
   else hipLaunchKernelGGL(k_dot<1>, dim3(nb), dim3(BS), 0, ctx->stream, x, y, N, ctx->d_partials);
   hipLaunchKernelGGL(k_reduce_to, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_partials, nb, ctx->d_scalars + slot);
+  SD_HIP(ctx, hipGetLastError());
+  return SD_OK;
+}
+
+// the same reductions filed at any device address (batched recursions keep one scalar pair per vector)
+int sd_k_dot_to(sd_ctx *ctx, int nc, const double *x, const double *y, int64_t N, double *dst_dev) {
+  int rc = sd_ensure_partials(ctx, 2 * RED_BLOCKS); if (rc) return rc;
+  int nb = (int)std::min<int64_t>(RED_BLOCKS, std::max<int64_t>(1, (N + BS - 1) / BS));
+  if (nc == 2) hipLaunchKernelGGL(k_dot<2>, dim3(nb), dim3(BS), 0, ctx->stream, x, y, N, ctx->d_partials);
+  else hipLaunchKernelGGL(k_dot<1>, dim3(nb), dim3(BS), 0, ctx->stream, x, y, N, ctx->d_partials);
+  hipLaunchKernelGGL(k_reduce_to, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_partials, nb, dst_dev);
+  SD_HIP(ctx, hipGetLastError());
+  return SD_OK;
+}
+int sd_k_nrm2sq_to(sd_ctx *ctx, const double *x, int64_t n, double *dst_dev) {
+  int rc = sd_ensure_partials(ctx, 2 * RED_BLOCKS); if (rc) return rc;
+  int nb = (int)std::min<int64_t>(RED_BLOCKS, std::max<int64_t>(1, (n + BS - 1) / BS));
+  hipLaunchKernelGGL(k_nrm2sq, dim3(nb), dim3(BS), 0, ctx->stream, x, n, ctx->d_partials);
+  hipLaunchKernelGGL(k_reduce_to, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_partials, nb, dst_dev);
   SD_HIP(ctx, hipGetLastError());
   return SD_OK;
 }
@@ -543,6 +629,39 @@ int sd_k_lanczos_fold(sd_ctx *ctx, double *t, const double *uc, const double *up
   hipLaunchKernelGGL(k, dim3(nb), dim3(BS), 0, ctx->stream, (double2 *)t, (const double2 *)uc, (const double2 *)up, N, dot_dev,
                      n2c_dev, n2p_dev, store_alpha, store_bc, ctx->d_partials);
   hipLaunchKernelGGL(k_reduce_to, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_partials, (int)nb, n2_out);
+  SD_HIP(ctx, hipGetLastError());
+  return SD_OK;
+}
+// launch-bound sizes (see k_lanczos_fold_p): `batch` vectors `bstride` elements apart; dotp: the apply's per-tile pairs (ndot per
+// vector), n2cp / n2pp: the per-block |w|^2 pairs of the two previous updates (nn2 per vector; null: normalised vector);
+// n2out receives *nb_out pairs per vector.  form 0 or 1.
+int sd_k_lanczos_fold_p(sd_ctx *ctx, double *t, const double *uc, const double *up, int64_t N, int batch, int64_t bstride, int form,
+                        const double *dotp, int ndot, const double *n2cp, const double *n2pp, int nn2, double *store_alpha,
+                        double *store_bc, int64_t store_stride, double *n2out, int nb) {
+  void (*k)(double2 *, const double2 *, const double2 *, int64_t, int64_t, const double *, int, const double *, const double *, int,
+            double *, double *, int64_t, double *) = nullptr;
+  switch (form * 2 + (up ? 1 : 0)) {
+    case 0: k = k_lanczos_fold_p<0, false>; break;
+    case 1: k = k_lanczos_fold_p<0, true>; break;
+    case 2: k = k_lanczos_fold_p<1, false>; break;
+    case 3: k = k_lanczos_fold_p<1, true>; break;
+    default: return sd_set_err(ctx, SD_EINTERNAL, "bad Lanczos update form");
+  }
+  hipLaunchKernelGGL(k, dim3((unsigned)nb, (unsigned)batch), dim3(BS), 0, ctx->stream, (double2 *)t, (const double2 *)uc,
+                     (const double2 *)up, N, bstride, dotp, ndot, n2cp, n2pp, nn2, store_alpha, store_bc, store_stride, n2out);
+  SD_HIP(ctx, hipGetLastError());
+  return SD_OK;
+}
+// few, fat blocks: every block first sums three partial lists (a few microseconds of latency whatever their length), so a block
+// should have at least ~2048 elements of its own; at most 256 blocks (= the length of the |w|^2 lists the next step sums)
+int sd_k_lanczos_fold_blocks(int64_t N) {
+  int64_t nb = (N + 2047) / 2048;
+  return (int)std::max<int64_t>(1, std::min<int64_t>(nb, 256));
+}
+int sd_k_lanczos_fold_scalars_p(sd_ctx *ctx, int batch, int form, const double *dotp, int ndot, const double *n2cp, int nn2,
+                                double *store_alpha, double *store_bc, int64_t store_stride) {
+  hipLaunchKernelGGL(k_lanczos_fold_scalars_p, dim3((unsigned)batch), dim3(BS), 0, ctx->stream, dotp, ndot, n2cp, nn2, form, store_alpha,
+                     store_bc, store_stride);
   SD_HIP(ctx, hipGetLastError());
   return SD_OK;
 }

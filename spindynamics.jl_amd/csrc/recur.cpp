@@ -155,6 +155,68 @@ int peek_breakdown(sd_ctx *ctx, const double *d_be, int count, double tol, std::
   return SD_OK;
 }
 
+// ---- Lanczos at launch-bound sizes: two launches per step, any number of start vectors per launch ----
+// The un-reorthogonalised recursion of lanczos_extremal (form 0, src/Lanczos.jl:27-84) and lanczos_tridiag (form 1, :196-246)
+// for Qb NORMALISED start vectors stored back to back in u0 (consumed): step j is one batched apply with the <u|Hu> epilogue,
+// its per-tile pairs left unreduced, and one batched update pass that sums those pairs and the previous passes' |w|^2 pairs
+// itself (k_lanczos_fold_p).  Nothing touches the host until the end.  alpha, beta: Qb rows of mm (beta[., mm-1] unused).
+// Same arithmetic per element as the four-launch form; the reductions are summed in another (fixed) order.
+bool lanczos_fused_ok(const Op &op, int Qb) {
+  const sd_model *m = op.m;
+  static const int on = getenv("SD_LANCZOS_FUSED") ? atoi(getenv("SD_LANCZOS_FUSED")) : 1;
+  return on && m->nranks == 1 && !op.ctx->user_apply && m->p >= 0 && m->dm.n_singles <= 4096 && op.n <= ((int64_t)1 << 22) &&
+         (int64_t)Qb * op.n * 16 * 3 <= ((int64_t)4 << 30);
+}
+int lanczos_fused(Op &op, int Qb, double *u0, int mm, int form, int negate, double tol, std::vector<double> &alpha,
+                  std::vector<double> &beta) {
+  sd_ctx *ctx = op.ctx;
+  const int64_t N = op.n;
+  const int nt = op.m->dm.n_singles, nbf = sd_k_lanczos_fold_blocks(N);
+  DBuf wb, vp, ab, n2;
+  RC(wb.alloc(ctx, 2 * N * Qb)); RC(vp.alloc(ctx, 2 * N * Qb));
+  const int64_t srow = 2 * (int64_t)mm;                                  // per vector: alpha[mm] | beta[mm]
+  RC(ab.alloc(ctx, srow * Qb)); RC(n2.alloc(ctx, 3 * 2 * (int64_t)nbf * Qb));
+  SD_HIP(ctx, hipMemsetAsync(ab.p, 0, sizeof(double) * (size_t)(srow * Qb), ctx->stream));
+  double *d_al = ab.p, *d_be = ab.p + mm;
+  auto n2buf = [&](int j) { return n2.p + (size_t)(j % 3) * 2 * (size_t)nbf * Qb; };
+  sd_epi_args ea; ea.negate = negate; ea.batch = Qb; ea.bstride = N; ea.no_reduce = 1;
+  double *ucur = u0, *uprev = vp.p, *t = wb.p;
+  std::vector<double> peek;
+  int queued = mm;
+  for (int j = 1; j <= mm; ++j) {
+    ctx->n_applies += Qb - 1;
+    RC(op.apply(SD_C128, t, ucur, SD_EPI_DOT, ea));                      // per-tile pairs of <u|Hu> -> ctx->d_partials
+    const double *n2c = j > 1 ? n2buf(j - 1) : nullptr, *n2p = j > 2 ? n2buf(j - 2) : nullptr;
+    if (j == mm) {                                                       // alpha_m; no vector behind it
+      RC(sd_k_lanczos_fold_scalars_p(ctx, Qb, form, ctx->d_partials, nt, n2c, nbf, d_al + (j - 1), j > 1 ? d_be + (j - 2) : nullptr, srow));
+      break;
+    }
+    RC(sd_k_lanczos_fold_p(ctx, t, ucur, j > 1 ? uprev : nullptr, N, Qb, N, form, ctx->d_partials, nt, n2c, n2p, nbf, d_al + (j - 1),
+                           j > 1 ? d_be + (j - 2) : nullptr, srow, n2buf(j), nbf));
+    { double *old = uprev; uprev = ucur; ucur = t; t = old; }
+    if (j % SD_BREAK_PEEK == 0 && j < mm - 1) {                          // stop queueing once EVERY vector has broken down
+      peek.resize((size_t)(srow * Qb));
+      SD_HIP(ctx, hipMemcpyAsync(peek.data(), ab.p, sizeof(double) * peek.size(), hipMemcpyDeviceToHost, ctx->stream));
+      SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      bool all_broke = true;
+      for (int q = 0; q < Qb && all_broke; ++q) {
+        bool broke = false;
+        for (int k = 0; k < j - 1; ++k) if (!(std::fabs(peek[(size_t)(srow * q) + mm + k]) >= tol)) { broke = true; break; }
+        all_broke = broke;
+      }
+      if (all_broke) { queued = j; break; }
+    }
+  }
+  (void)queued;
+  std::vector<double> host((size_t)(srow * Qb));
+  SD_HIP(ctx, hipMemcpyAsync(host.data(), ab.p, sizeof(double) * host.size(), hipMemcpyDeviceToHost, ctx->stream));
+  SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  alpha.assign((size_t)Qb * mm, 0.0); beta.assign((size_t)Qb * mm, 0.0);
+  for (int q = 0; q < Qb; ++q)
+    for (int k = 0; k < mm; ++k) { alpha[(size_t)q * mm + k] = host[(size_t)(srow * q) + k]; beta[(size_t)q * mm + k] = host[(size_t)(srow * q) + mm + k]; }
+  return SD_OK;
+}
+
 // lanczos_extremal on device vectors; v_prev (2n doubles, un-normalised start) is consumed
 int extremal_dev(Op &op, int lanc_m, double tol, double *v_prev, int negate, double *emin, double *emax) {
   sd_ctx *ctx = op.ctx;
@@ -167,6 +229,18 @@ int extremal_dev(Op &op, int lanc_m, double tol, double *v_prev, int negate, dou
   int rc = 0;
   double nrm = norm_dev(op, v_prev, 2 * N, &rc); RC(rc);
   RC(sd_k_scale_div(ctx, v_prev, v_prev, 2 * N, nrm));                     // :40
+  if (lanczos_fused_ok(op, 1)) {                                           // launch-bound sizes: two launches per step
+    std::vector<double> al, be;
+    RC(lanczos_fused(op, 1, v_prev, mm, 0, negate, tol, al, be));
+    int actual = mm;
+    for (int j = 1; j < mm; ++j)
+      if (!(be[j - 1] >= tol)) { actual = j; break; }                      // :66-70
+    std::vector<double> ev(actual);
+    if (sd_symtridiag_eig(actual, al.data(), be.data(), ev.data(), nullptr))   // :80-83
+      return sd_set_err(ctx, SD_EINTERNAL, "tridiagonal eigen-solver did not converge");
+    *emin = ev[0]; *emax = ev[actual - 1];
+    return SD_OK;
+  }
   // the loop is queued without host round trips (alpha_j, beta_j stay on the device, see tridiag_dev); the break on
   // beta_j < tol (:66-70) is applied to the values read back at the end.  Vectors stay un-normalised (k_lanczos_fold).
   DBuf ab; RC(ab.alloc(ctx, 4 * (int64_t)mm + 2));
@@ -285,6 +359,71 @@ int moments_dev(Op &op, const double *phi, int M, double a, double b, double *mu
   return SD_OK;
 }
 
+// compute_chebyshev_moments (src/KPM_Sqw.jl:95-128) for Qb normalised vectors AT ONCE: phi = Qb vectors of n elements stored
+// back to back.  The reference threads over the momenta (src/KPM_Sqw.jl:218); where one vector cannot fill the chip (its own
+// documented sizes: L = 16..20) a recursion step per momentum is a launch-bound 5-10 us whatever it computes, so the momenta's
+// vectors share the launches instead: one batched apply + one batched reduction per step for all of them (sd_epi_args::batch).
+// Every vector sees exactly the arithmetic of moments_dev -- same kernels per tile, same summation order -- so mu is
+// bit-identical to the one-momentum-at-a-time loop.  ok[k] = 0: the reference's overflow guard (:118-121) would have fired for
+// vector k; the caller reruns it through moments_dev.  Unsharded tiled plans only (the caller checks).
+int moments_dev_batched(Op &op, const double *phi, int Qb, int M, double a, double b, double *mu /* Qb x M */, std::vector<char> &ok) {
+  sd_ctx *ctx = op.ctx;
+  const int64_t N = op.n;
+  if (M < 2) return sd_set_err(ctx, SD_EARG, "kpm_m must be >= 2");
+  ok.assign((size_t)Qb, 1);
+  const bool doubling = ctx->kpm_doubling != 0;
+  const int nsteps = doubling ? M / 2 : M - 1;                  // applies: v_1 .. v_nsteps
+  DBuf b0, b1, b2, sm;
+  RC(b0.alloc(ctx, 2 * N * Qb)); RC(b1.alloc(ctx, 2 * N * Qb)); RC(b2.alloc(ctx, 2 * N * Qb));
+  RC(sm.alloc(ctx, (int64_t)Qb * (2 * (int64_t)nsteps + 2)));
+  const int64_t srow = 2 * (int64_t)nsteps + 2;                  // per vector: [mu0, 0, (s0, s1) of step 1, 2, ...]
+  double *v_prev = b0.p, *v_curr = b1.p, *v_next = b2.p;
+  RC(d2d(ctx, v_prev, phi, 2 * N * Qb));
+  for (int k = 0; k < Qb; ++k) RC(sd_k_dot_to(ctx, 2, phi + 2 * N * k, v_prev + 2 * N * k, N, sm.p + srow * k));     // :103
+  sd_epi_args ea; ea.a = a; ea.b = b;
+  ea.batch = Qb; ea.bstride = N; ea.sums_bstride = srow;
+  ea.phi = doubling ? nullptr : phi;                            // doubling: s0 = Re<v_curr|v_next>; reference loop: Re<phi|v_next>
+  ea.sums_dst = sm.p + 2;
+  ctx->n_applies += Qb - 1;                                     // (Op::apply counts one)
+  RC(op.apply(SD_C128, v_curr, v_prev, SD_EPI_RESCALE_DOT, ea));                                    // :106-107
+  for (int n = 1; n < nsteps; ++n) {
+    ea.prev = v_prev; ea.sums_dst = sm.p + 2 + 2 * n;
+    ctx->n_applies += Qb - 1;
+    RC(op.apply(SD_C128, v_next, v_curr, SD_EPI_KPM, ea));                                          // :111-117 fused
+    double *t = v_prev; v_prev = v_curr; v_curr = v_next; v_next = t;                               // :124
+  }
+  std::vector<double> hs((size_t)Qb * (size_t)srow);
+  SD_HIP(ctx, hipMemcpyAsync(hs.data(), sm.p, sizeof(double) * hs.size(), hipMemcpyDeviceToHost, ctx->stream));
+  SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (int q = 0; q < Qb; ++q) {
+    const double *h = hs.data() + (size_t)q * (size_t)srow;
+    double *m = mu + (size_t)q * (size_t)M;
+    m[0] = h[0];
+    for (int k = 1; k <= nsteps; ++k) {                         // sums of step k: [s0, |v_k|^2]
+      const double s0 = h[2 * (size_t)k], s1 = h[2 * (size_t)k + 1];
+      if (doubling) {
+        if (k == 1) m[1] = s0;
+        else if (2 * k - 1 <= M - 1) m[2 * k - 1] = 2.0 * s0 - m[1];
+        if (2 * k <= M - 1) m[2 * k] = 2.0 * s1 - m[0];
+      } else {
+        m[k] = s0;
+      }
+      if (!(std::sqrt(s1) <= 1e3)) ok[q] = 0;                   // the reference would have renormalised v_next here
+    }
+  }
+  return SD_OK;
+}
+
+// the reference's break on beta_j < tol (src/Lanczos.jl:228-231; NaN counts as a break) applied to the read-back coefficients
+void tridiag_trim(int mm, double tol, const double *al, const double *be, double *alpha, double *beta, int *m_eff_out) {
+  int m_eff = mm;
+  for (int j = 1; j <= mm - 1; ++j)
+    if (!(be[j - 1] >= tol)) { m_eff = j; break; }
+  for (int k = 0; k < mm; ++k) alpha[k] = k < m_eff ? al[k] : 0.0;
+  for (int k = 0; k + 1 < mm; ++k) beta[k] = (m_eff < mm ? k < m_eff : k < mm - 1) ? be[k] : 0.0;
+  *m_eff_out = m_eff;
+}
+
 int tridiag_dev(Op &op, double *vcur /* normalised start, consumed */, int lanc_m, double tol,
                 double *alpha, double *beta, int *m_eff_out) {
   // lanczos_tridiag  src/Lanczos.jl:196-246 with two live vectors (the reference keeps all m).
@@ -295,6 +434,12 @@ int tridiag_dev(Op &op, double *vcur /* normalised start, consumed */, int lanc_
   sd_ctx *ctx = op.ctx;
   const int64_t n = op.n;
   const int mm = (int)std::min<int64_t>(lanc_m, op.m->N);
+  if (lanczos_fused_ok(op, 1)) {                                           // launch-bound sizes: two launches per step
+    std::vector<double> al, be;
+    RC(lanczos_fused(op, 1, vcur, mm, 1, 0, tol, al, be));
+    tridiag_trim(mm, tol, al.data(), be.data(), alpha, beta, m_eff_out);
+    return SD_OK;
+  }
   DBuf wb, vp, ab;
   RC(wb.alloc(ctx, 2 * n)); RC(vp.alloc(ctx, 2 * n)); RC(ab.alloc(ctx, 4 * (int64_t)mm + 2));
   double *d_al = ab.p, *d_be = ab.p + mm, *d_n2 = ab.p + 2 * (int64_t)mm;      // d_n2[2j]: |w_j|^2
@@ -326,12 +471,7 @@ int tridiag_dev(Op &op, double *vcur /* normalised start, consumed */, int lanc_
   std::vector<double> host(2 * (size_t)mm);
   SD_HIP(ctx, hipMemcpyAsync(host.data(), ab.p, sizeof(double) * 2 * (size_t)mm, hipMemcpyDeviceToHost, ctx->stream));
   SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  int m_eff = mm;
-  for (int j = 1; j <= mm - 1; ++j)
-    if (!(host[mm + j - 1] >= tol)) { m_eff = j; break; }                                          // :228-231 (NaN counts as a break)
-  for (int k = 0; k < mm; ++k) alpha[k] = k < m_eff ? host[k] : 0.0;
-  for (int k = 0; k + 1 < mm; ++k) beta[k] = (m_eff < mm ? k < m_eff : k < mm - 1) ? host[mm + k] : 0.0;
-  *m_eff_out = m_eff;
+  tridiag_trim(mm, tol, host.data(), host.data() + mm, alpha, beta, m_eff_out);
   return SD_OK;
 }
 
@@ -968,6 +1108,57 @@ static int kpm_sqw_core(Op &op, int dtype, const void *psi0, bool on_dev, int64_
   // every pair (q, 2 pi - q) of the list is computed once for a real psi0 (pair_momenta)
   std::vector<int> same_as;
   RC(pair_momenta(op, dtype, psic.p, n, q, Qn, same_as));
+  // Launch-bound sizes: the momenta's vectors share their launches (moments_dev_batched).  sd_ctx_set_q_batch(ctx, 0): one momentum at a time.
+  {
+    std::vector<int> live;
+    for (int iq = 0; iq < Qn; ++iq) if (same_as[iq] < 0) live.push_back(iq);
+    const int q_batch = ctx->q_batch;
+    const int Qb = (int)live.size();
+    // five batches of vectors (phi + the recursion's three + nothing else) within 4 GiB, vectors of at most 2^22 rows
+    const bool batched = q_batch && Qb >= 2 && m->nranks == 1 && !ctx->user_apply && m->p >= 0 && m->dm.n_singles <= 16384 &&
+                         n <= ((int64_t)1 << 22) && (int64_t)Qb * n * 16 * 4 <= ((int64_t)4 << 30);
+    if (batched) {
+      DBuf phib, nrm;
+      RC(phib.alloc(ctx, 2 * n * Qb)); RC(nrm.alloc(ctx, 2 * (int64_t)Qb));
+      for (int k = 0; k < Qb; ++k) {
+        RC(sd_launch_szq(ctx, m, SD_C128, psic.p, q[live[k]], phib.p + 2 * n * k));       // :223
+        RC(sd_k_nrm2sq_to(ctx, phib.p + 2 * n * k, 2 * n, nrm.p + 2 * k));
+      }
+      std::vector<double> hn(2 * (size_t)Qb);
+      SD_HIP(ctx, hipMemcpyAsync(hn.data(), nrm.p, sizeof(double) * hn.size(), hipMemcpyDeviceToHost, ctx->stream));
+      SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      // zero vectors (:226-229) drop out of the batch; the rest are normalised in place (:231)
+      std::vector<int> kept; std::vector<double> norms;
+      for (int k = 0; k < Qb; ++k) {
+        const double nphi = std::sqrt(hn[2 * (size_t)k]);
+        double *Srow = Smat + (size_t)live[k] * W;
+        if (nphi == 0) { for (int iw = 0; iw < W; ++iw) Srow[iw] = 0.0; continue; }
+        const int dst = (int)kept.size();
+        if (dst != k) RC(d2d(ctx, phib.p + 2 * n * dst, phib.p + 2 * n * k, 2 * n));
+        RC(sd_k_scale_div(ctx, phib.p + 2 * n * dst, phib.p + 2 * n * dst, 2 * n, nphi));
+        kept.push_back(live[k]); norms.push_back(nphi);
+      }
+      const int Qk = (int)kept.size();
+      if (Qk > 0) {
+        std::vector<double> mub((size_t)Qk * (size_t)kpm_m);
+        std::vector<char> okv;
+        RC(moments_dev_batched(op, phib.p, Qk, kpm_m, a, b, mub.data(), okv));
+        for (int k = 0; k < Qk; ++k) {
+          double *Srow = Smat + (size_t)kept[k] * W;
+          double *muk = mub.data() + (size_t)k * (size_t)kpm_m;
+          if (!okv[k]) RC(moments_dev(op, phib.p + 2 * n * k, kpm_m, a, b, muk));          // the guard fired: the reference's loop
+          for (int j = 0; j < kpm_m; ++j) muk[j] *= g[j];                                 // :53
+          sd_kpm_reconstruct(muk, kpm_m, omega, W, a, b, E0, Srow);
+          const double n2 = norms[k] * norms[k];
+          for (int iw = 0; iw < W; ++iw) Srow[iw] *= n2;                                  // :252
+        }
+      }
+      for (int iq = 0; iq < Qn; ++iq)
+        if (same_as[iq] >= 0) std::memcpy(Smat + (size_t)iq * W, Smat + (size_t)same_as[iq] * W, sizeof(double) * (size_t)W);
+      SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      return SD_OK;
+    }
+  }
   for (int iq = 0; iq < Qn; ++iq) {                                                       // :218 (serial over q)
     double *Srow = Smat + (size_t)iq * W;
     if (same_as[iq] >= 0) {
@@ -1035,6 +1226,47 @@ static int sd_lanczos_sqw_impl(sd_ctx *ctx, const sd_model *m, int dtype, const 
   int rc = 0;
   std::vector<int> same_as;
   RC(pair_momenta(op, dtype, psic.p, n, q, Qn, same_as));      // real psi0: the Lanczos coefficients of q and 2 pi - q agree
+  {   // launch-bound sizes: all momenta in one recursion (src/LanczosSqw.jl:65 threads over them)
+    std::vector<int> live;
+    for (int iq = 0; iq < Qn; ++iq) if (same_as[iq] < 0) live.push_back(iq);
+    const int Qb = (int)live.size();
+    if (ctx->q_batch && Qb >= 2 && lanczos_fused_ok(op, Qb)) {
+      DBuf phib, nrm;
+      RC(phib.alloc(ctx, 2 * n * Qb)); RC(nrm.alloc(ctx, 2 * (int64_t)Qb));
+      for (int k = 0; k < Qb; ++k) {
+        RC(sd_launch_szq(ctx, m, SD_C128, psic.p, q[live[k]], phib.p + 2 * n * k));
+        RC(sd_k_nrm2sq_to(ctx, phib.p + 2 * n * k, 2 * n, nrm.p + 2 * k));
+      }
+      std::vector<double> hn(2 * (size_t)Qb);
+      SD_HIP(ctx, hipMemcpyAsync(hn.data(), nrm.p, sizeof(double) * hn.size(), hipMemcpyDeviceToHost, ctx->stream));
+      SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      std::vector<int> kept; std::vector<double> norms;
+      for (int k = 0; k < Qb; ++k) {
+        const double nphi = std::sqrt(hn[2 * (size_t)k]);
+        double *Srow = Smat + (size_t)live[k] * W;
+        if (nphi == 0) { for (int iw = 0; iw < W; ++iw) Srow[iw] = 0.0; continue; }       // :67-70
+        const int dst = (int)kept.size();
+        if (dst != k) RC(d2d(ctx, phib.p + 2 * n * dst, phib.p + 2 * n * k, 2 * n));
+        RC(sd_k_scale_div(ctx, phib.p + 2 * n * dst, phib.p + 2 * n * dst, 2 * n, nphi));
+        kept.push_back(live[k]); norms.push_back(nphi);
+      }
+      const int Qk = (int)kept.size();
+      if (Qk > 0) {
+        std::vector<double> al, be;
+        RC(lanczos_fused(op, Qk, phib.p, mm, 1, 0, 1e-12, al, be));                       // :73
+        for (int k = 0; k < Qk; ++k) {
+          int m_eff = 0;
+          tridiag_trim(mm, 1e-12, al.data() + (size_t)k * mm, be.data() + (size_t)k * mm, alpha.data(), beta.data(), &m_eff);
+          int rs = sd_spectral_from_tridiagonal(alpha.data(), beta.data(), m_eff, norms[k], E0, omega, W, eta, broaden,
+                                                Smat + (size_t)kept[k] * W);
+          if (rs) return sd_set_err(ctx, rs, "spectral_from_tridiagonal failed");
+        }
+      }
+      for (int iq = 0; iq < Qn; ++iq)
+        if (same_as[iq] >= 0) std::memcpy(Smat + (size_t)iq * W, Smat + (size_t)same_as[iq] * W, sizeof(double) * (size_t)W);
+      return SD_OK;
+    }
+  }
   for (int iq = 0; iq < Qn; ++iq) {
     double *Srow = Smat + (size_t)iq * W;
     if (same_as[iq] >= 0) { std::memcpy(Srow, Smat + (size_t)same_as[iq] * W, sizeof(double) * (size_t)W); continue; }

@@ -70,6 +70,7 @@ struct sd_ctx {
   void *user_apply_data = nullptr;
   int64_t n_applies = 0;    // operator applications the recursion-level entries have queued on this context (sd_ctx_apply_count)
   int gs_blocked = 1;       // sd_ctx_set_gs_blocked: lanczos_groundstate re-orthogonalises in blocks of 8 columns (default) or column by column as the reference
+  int q_batch = 1;          // sd_ctx_set_q_batch: the momenta of S(q,w) share the launches of their recursions at launch-bound sizes
   int kpm_pair_q = 1;       // sd_ctx_set_kpm_pair_q: for a real psi0 compute S(q,w) once per pair (q, 2pi - q) and copy the row
 };
 
@@ -207,6 +208,14 @@ struct sd_epi_args {
   int stream_hint = 0;          // set by sd_launch_apply: bit 0 non-temporal stores of out, bit 1 non-temporal side streams (prev, phi, psi_t); env SD_STREAM_HINT
   double *sums_dst = nullptr;   // where the two reduced sums of a DOT / KPM / RESCALE_DOT epilogue go (device; null: ctx->d_scalars[0..1])
   const void *halo = nullptr;   // sharded plans: imported partner tiles (offsets >= n_local); null = halo follows psi's owned rows
+  // Batched launch (k_apply_tiled, unsharded tiled plans): grid.y = batch vectors stored `bstride` ELEMENTS apart -- psi, out,
+  // prev, phi and accv alike -- run through the same operator in one launch (the reference threads over the momenta of S(q,w),
+  // src/KPM_Sqw.jl:218, src/LanczosSqw.jl:65; here the momenta's vectors share a launch where one vector cannot fill the chip).
+  // The two sums of vector k go to sums_dst + k * sums_bstride.  Every vector sees exactly the arithmetic of a launch of its own.
+  int batch = 1;
+  int64_t bstride = 0;
+  int64_t sums_bstride = 2;
+  int no_reduce = 0;            // sum epilogues: leave the per-tile pairs in ctx->d_partials (n_singles per vector), the consumer sums them
 };
 // Launches the apply with the chosen epilogue.  When the epilogue produces
 // partial sums, the reduced values land in ctx->d_scalars[0..1] (device).
@@ -227,10 +236,18 @@ int sd_launch_szq(sd_ctx *ctx, const sd_model *m, int dtype_in, const void *psi0
 int sd_k_dot(sd_ctx *ctx, int nc, const double *x, const double *y, int64_t N, int slot);  // conj(x).y -> [slot]=re,[slot+1]=im
 int sd_k_dotu(sd_ctx *ctx, const double *x, const double *y, int64_t N, int slot);          // complex sum x_i*y_i, NO conjugation -> [slot]=re,[slot+1]=im
 int sd_k_nrm2sq(sd_ctx *ctx, const double *x, int64_t n, int slot);
+int sd_k_dot_to(sd_ctx *ctx, int nc, const double *x, const double *y, int64_t N, double *dst_dev);    // -> dst_dev[0..1] (any device address)
+int sd_k_nrm2sq_to(sd_ctx *ctx, const double *x, int64_t n, double *dst_dev);                       // -> dst_dev[0..1]
 int sd_k_imag_count(sd_ctx *ctx, const double *xc, int64_t N, int slot);   // ComplexF64 elements with Im != 0 -> d_scalars[slot] (d_scalars[slot+1] = 0)
 // three-term update on un-normalised Lanczos vectors (kernels_blas1.hip, k_lanczos_fold): t <- w, |w|^2 -> n2_out[0..1]
 int sd_k_lanczos_fold(sd_ctx *ctx, double *t, const double *uc, const double *up, int64_t N, int form, const double *dot_dev,
                       const double *n2c_dev, const double *n2p_dev, double *store_alpha, double *store_bc, double *n2_out);
+int sd_k_lanczos_fold_p(sd_ctx *ctx, double *t, const double *uc, const double *up, int64_t N, int batch, int64_t bstride, int form,
+                        const double *dotp, int ndot, const double *n2cp, const double *n2pp, int nn2, double *store_alpha,
+                        double *store_bc, int64_t store_stride, double *n2out, int nb);
+int sd_k_lanczos_fold_blocks(int64_t N);     // blocks (= |w|^2 partial pairs per vector) of sd_k_lanczos_fold_p for N elements
+int sd_k_lanczos_fold_scalars_p(sd_ctx *ctx, int batch, int form, const double *dotp, int ndot, const double *n2cp, int nn2,
+                                double *store_alpha, double *store_bc, int64_t store_stride);
 int sd_k_build_diag(const sd_dev_model &dm, double *out);   // out[local row] = diag_of(row) through the tile tables; synchronous
 int sd_k_lanczos_fold_scalars(sd_ctx *ctx, int form, const double *dot_dev, const double *n2c_dev, double *store_alpha,
                               double *store_bc);
@@ -261,6 +278,8 @@ double sd_randn_host(uint64_t seed, uint64_t k);
 // doubles of ctx->d_partials (long lists are summed in two stages)
 #define SD_RED_STAGE_BLOCKS 512
 int sd_reduce_pairs(sd_ctx *ctx, int64_t n, double *dst);
+// the same for `batch` lists of n pairs stored back to back (n <= 16384): list k -> dst + k * dstride
+int sd_reduce_pairs_batched(sd_ctx *ctx, int64_t n, int batch, double *dst, int64_t dstride);
 // ---- communicators (comm.cpp): all three are no-ops for a null communicator or an unsharded model ----
 int sd_comm_nranks(const sd_comm *c);
 int sd_comm_exchange_start(sd_ctx *ctx, sd_comm *c, const sd_model *m, int dtype, const void *src, void *halo);

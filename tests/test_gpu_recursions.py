@@ -182,6 +182,70 @@ def test_kpm_and_sqw_vs_oracle(pkg, O, L, nup, Jxy, Jz, bc):
     assert np.abs(Sg - O.lanczos_sqw(r, gs, q[1:2], omega, lanc_m=12, eta=0.1, broaden="gauss")).max() <= 1e-8
 
 
+def test_kpm_sqw_momenta_in_one_batch_equal_one_momentum_at_a_time(pkg, O):
+    """At launch-bound sizes the momenta's vectors share every launch of the moment recursion (sd_ctx_set_q_batch, default on;
+    the reference threads over q, src/KPM_Sqw.jl:218).  Each vector sees exactly the arithmetic of a recursion of its own, so S(q, w)
+    must be EQUAL -- to the bit -- to the one-momentum-at-a-time loop: for both moment routes, a real psi0 (paired momenta), a complex
+    one (every q on its own, q = 0 dropping out of the batch as a zero vector), and bounds that make the reference's overflow guard
+    fire for every momentum (the batch then hands each vector to the one-at-a-time recursion)."""
+    L, nup = 14, 7
+    m = pkg.XXZChain(L, nup=nup, Jz=0.9)
+    r = O.XXZChain(L, nup=nup, Jz=0.9)
+    x0 = np.random.default_rng(12).standard_normal(m.N)
+    _, gs = O.lanczos_groundstate(r, x0, lanc_m=60)
+    q = pkg.momenta(m)
+    omega = np.arange(0.0, 4.0, 0.05)
+    a, b = O.rescaling_from_bounds(-L / 2, L / 2)
+    cases = [(gs, a, b, 65), (cvec(m.N, 3), a, b, 32), (gs, 0.6, 0.0, 24)]
+    try:
+        for doubling in (True, False):
+            m.ctx.set_kpm_doubling(doubling)
+            for psi0, aa, bb, M in cases:
+                m.ctx.set_q_batch(True)
+                n0 = m.ctx.apply_count()
+                S_batch = pkg.kpm_sqw(psi0, m, q, omega, a=aa, b=bb, kpm_m=M)
+                n_batch = m.ctx.apply_count() - n0
+                m.ctx.set_q_batch(False)
+                n0 = m.ctx.apply_count()
+                S_serial = pkg.kpm_sqw(psi0, m, q, omega, a=aa, b=bb, kpm_m=M)
+                n_serial = m.ctx.apply_count() - n0
+                assert np.array_equal(S_batch, S_serial), (doubling, M)
+                if aa == a:
+                    assert n_batch == n_serial                       # the same operator applications, in fewer launches
+                    assert np.abs(S_batch - O.kpm_sqw(r, psi0, q, omega, aa, bb, kpm_m=M)).max() <= 1e-8 * max(1.0, np.abs(S_batch).max())
+    finally:
+        m.ctx.set_kpm_doubling(True)
+        m.ctx.set_q_batch(True)
+
+
+def test_lanczos_sqw_momenta_in_one_batch_equal_one_momentum_at_a_time(pkg, O):
+    """lanczos_sqw (src/LanczosSqw.jl:49-80; the reference threads over q, :65): at launch-bound sizes all momenta run in ONE
+    recursion of two launches per step (a batched apply + a batched update pass that sums the partial lists itself).  Each
+    vector's coefficients are those of a recursion of its own -- S equal to the bit -- and agree with the oracle."""
+    L, nup = 14, 7
+    m = pkg.XXZChain(L, nup=nup, Jz=1.1)
+    r = O.XXZChain(L, nup=nup, Jz=1.1)
+    x0 = np.random.default_rng(13).standard_normal(m.N)
+    _, gs = O.lanczos_groundstate(r, x0, lanc_m=60)
+    q = pkg.momenta(m)
+    omega = np.arange(0.0, 4.0, 0.05)
+    try:
+        for psi0 in (gs, cvec(m.N, 4)):
+            m.ctx.set_q_batch(True)
+            n0 = m.ctx.apply_count()
+            S_batch = pkg.lanczos_sqw(psi0, m, q, omega, lanc_m=12, eta=0.05)
+            n_batch = m.ctx.apply_count() - n0
+            m.ctx.set_q_batch(False)
+            n0 = m.ctx.apply_count()
+            S_serial = pkg.lanczos_sqw(psi0, m, q, omega, lanc_m=12, eta=0.05)
+            assert np.array_equal(S_batch, S_serial)
+            assert n_batch == m.ctx.apply_count() - n0
+            S2 = O.lanczos_sqw(r, psi0, q, omega, lanc_m=12, eta=0.05)
+            assert np.abs(S_batch - S2).max() <= 1e-8 * max(1.0, np.abs(S2).max())
+    finally:
+        m.ctx.set_q_batch(True)
+
+
 @pytest.mark.parametrize("M", [2, 3, 4, 7, 64, 201])
 def test_kpm_moment_doubling_equals_reference_loop(pkg, O, M):
     """Default: two moments per apply (mu_2n = 2<v_n|v_n> - mu_0, mu_2n+1 = 2Re<v_n|v_n+1> - mu_1).  It must give the
