@@ -150,68 +150,27 @@ def kernel_name(device_path, dtype):
     return "k_apply_generic" + t
 
 
-def c_rccl_path(pkg, op, src, dst, steps, dist, backend, dev, rank, all_ok, on_timeout):
-    """The same steps once more through sd_apply_sharded on the library's own RCCL communicator (csrc/comm.cpp: pack,
-    grouped ncclSend/ncclRecv on a second stream, interior tiles meanwhile, boundary tiles after the halo) instead of
-    torch.distributed issued from Python.  Returns ms per step, or a string saying why there is no number.  If RCCL never
-    returns, a watchdog calls on_timeout() -- rank 0 prints the headline line without this figure -- and ends the process
-    with status 3, so that the launcher and the driver see that the RCCL leg hung."""
-    import ctypes as C
+def with_watchdog(fn, rank, on_timeout):
+    """Run fn() with a watchdog: a collective of the library's RCCL path that never returns must not hang the run.  After
+    SD_BENCH_RCCL_TIMEOUT seconds on_timeout() is called (rank 0 prints the line it already has) and the process ends with
+    status 3, so that the launcher and the driver see that this leg hung."""
     import threading
-    import torch
-    if backend != "nccl":
-        return "not run: backend %s (the ranks share one GPU; RCCL needs one GPU per rank)" % backend
     limit = float(os.environ.get("SD_BENCH_RCCL_TIMEOUT", "120"))
     done = threading.Event()
 
     def watchdog():
         if not done.wait(limit):
-            sys.stderr.write("rank %d: the C RCCL path did not finish within %.0f s; giving up on it\n" % (rank, limit))
+            sys.stderr.write("rank %d: the library's communication path did not finish within %.0f s; giving up on it\n" % (rank, limit))
             sys.stderr.flush()
             on_timeout()
             sys.stdout.flush()
             os._exit(3)      # the headline line is out, but a hung collective must not read as a green run
-    comm = None
+    th = threading.Thread(target=watchdog, daemon=True)
+    th.start()
     try:
-        from spindynamics_jl_amd.dist import RcclComm
-        th = threading.Thread(target=watchdog, daemon=True)
-        th.start()
-        comm = RcclComm(op, dev)
-        m = op.model
-        lib = pkg.lib()
-        code = 2 if src.is_complex() else 1
-        m.ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
-        pkg.check(lib.sd_comm_selftest(m.ctx.h, comm.h), m.ctx.h)
-        ref = torch.empty_like(dst)
-        op.apply(ref, src)
-        pkg.check(lib.sd_apply_sharded(m.ctx.h, m.h, comm.h, code, dst.data_ptr(), src.data_ptr(), op.n_local, 1), m.ctx.h)
-        torch.cuda.synchronize()
-        same = bool(torch.equal(ref, dst))
-        del ref
-        if not all_ok(same):
-            return "ran, but its result differs from the torch.distributed path: not timed"
-        dist.barrier()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        x, y = src, dst
-        for _ in range(steps):
-            pkg.check(lib.sd_apply_sharded(m.ctx.h, m.h, comm.h, code, y.data_ptr(), x.data_ptr(), op.n_local, 1), m.ctx.h)
-            x, y = y, x
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / steps
-        t = torch.tensor([ms], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item())
-    except Exception as e:     # noqa: BLE001 -- a diagnostic leg: never a reason to lose the headline
-        return "failed: %r" % (e,)
+        return fn()
     finally:
         done.set()
-        if comm is not None:
-            try:
-                comm.close()
-            except Exception:
-                pass
 
 
 def main():
@@ -372,30 +331,36 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    src, dst = a, b
-    for _ in range(args.warmup):
-        op.apply(dst, src)
-        src, dst = dst, src
-    sync()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # per-step device times (median / min)
-    t0 = time.perf_counter()
-    ev0.record()
-    marks[0].record()
-    for k in range(args.steps):
-        op.apply(dst, src)
-        src, dst = dst, src
-        marks[k + 1].record()
-    ev1.record()
-    sync()
-    t1 = time.perf_counter()
-    step_ms = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps))
-    elapsed = t1 - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    ev_ms = ev0.elapsed_time(ev1) / args.steps  # per step, device time on the launch stream
+    def timed(apply_fn, src, dst):
+        """W untimed + K timed steps of apply_fn(dst, src) bracketed by barrier + synchronize; the MAX over the ranks of the
+        wall time, the device time per step on the launch stream, the sorted per-step device times, and where src / dst ended."""
+        for _ in range(args.warmup):
+            apply_fn(dst, src)
+            src, dst = dst, src
+        sync()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # per-step device times (median / min)
+        t0 = time.perf_counter()
+        ev0.record()
+        marks[0].record()
+        for k in range(args.steps):
+            apply_fn(dst, src)
+            src, dst = dst, src
+            marks[k + 1].record()
+        ev1.record()
+        sync()
+        t1 = time.perf_counter()
+        step_ms = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps))
+        elapsed = t1 - t0
+        if dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed, ev0.elapsed_time(ev1) / args.steps, step_ms, src, dst
+
+    # the Python-issued path (pack kernel, torch.distributed batch_isend_irecv, interior / boundary launches): always measured
+    elapsed, ev_ms, step_ms, src, dst = timed(lambda d, s_: op.apply(d, s_), a, b)
+    path_used = "python: torch.distributed point-to-point issued per step" if world > 1 else "single rank"
 
     # kernel-only timing (no exchange) for the roofline of the dominant kernel: HIP events around K launches
     kern_ms = ev_ms
@@ -409,8 +374,8 @@ def main():
         torch.cuda.synchronize()
         kern_ms = e0.elapsed_time(e1) / args.steps
 
-    # ---- N > 1: where a step's time goes on every rank, and the same steps through the library's own RCCL path ----
-    per_rank, c_rccl = None, None
+    # ---- N > 1: where a step's time goes on every rank ----
+    per_rank = None
     if world > 1:
         prof = [op.apply_profiled(dst, src) for _ in range(3)][-1]
         prof["rank"] = rank
@@ -421,7 +386,7 @@ def main():
         per_rank = [None] * world
         dist.all_gather_object(per_rank, prof)
 
-    if rank == 0:
+    def build_line(elapsed, step_ms, path_used, library_path):
         N = model.N
         ms_per_step = elapsed / args.steps * 1e3
         alg_bytes = op.n_local * 2 * esize               # read psi[idx] once + write out[idx] once
@@ -444,7 +409,7 @@ def main():
                         traffic_source = "profiles/traffic_latest.json is stale (kernel sources changed since it was measured): null"
             except Exception:
                 traffic = None
-        line = {
+        return {
             "metric": "H|psi> matvecs/s, XXZ L=%d Sz=0" % L,
             "value": args.steps / elapsed,
             "unit": "matvecs/s",
@@ -459,13 +424,15 @@ def main():
             "dtype": args.dtype,
             "data": "synthetic: counter-based N(0,1) psi keyed by (seed=%d, global index), normalised" % SEED,
             "config": {"workload": "XXZChain(L=%d, nup=%d) open, Jxy=Jz=1, hz=0: out <- H psi, %s, N=%d, per-row summation in the "
-                                   "reference's order (bit-identical to the CPU oracle; the order-relaxed two-pass form was probed and is "
-                                   "slower: DESIGN section 5); %s shards, %d rank(s), halo exchange per step"
+                                   "reference's order (bit-identical to the CPU oracle); %s shards, %d rank(s), halo exchange per step"
                                    % (L, nup, "ComplexF64" if args.dtype == "c128" else "Float64", N,
                                       "popcount-cell" if op.mode == "class" else "basis-index-range", world),
                        "rows_per_rank": op.n_local, "halo_rows_rank0": op.n_halo, "shard_mode": op.mode,
                        "device_path": model.device_path,
-                       "halo_routing": halo_routing, "per_rank_ms": per_rank, "c_rccl_path_ms": c_rccl},
+                       "halo_routing": halo_routing, "per_rank_ms": per_rank,
+                       # which path the headline was timed on, and the other one beside it (N > 1): the library's own sharded step
+                       # (sd_apply_sharded on its RCCL communicator -- what every sharded recursion runs) or the Python-issued one
+                       "path": path_used, "library_path": library_path},
             "selfcheck": check,
             "achieved_hbm_GBs_per_gpu": achieved,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -484,16 +451,51 @@ def main():
                          "kernel": kernel_name(model.device_path, args.dtype),
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes},
         }
-    else:
-        line = None
+
+    line = build_line(elapsed, step_ms, path_used, None) if rank == 0 else None
     if world > 1:
+        # ---- the library's own sharded step: sd_apply_sharded on the communicator ShardedOperator.comm() settles on (RCCL itself
+        # under an NCCL process group, after its self-test on every rank; torch.distributed callbacks otherwise).  Checked bit for
+        # bit against the Python-issued step before it is timed; when it passes, IT is the headline (it is what every sharded
+        # recursion runs) and the Python-issued figure is reported beside it.
         def on_timeout():
             if rank == 0:
-                line["config"]["c_rccl_path_ms"] = "timeout: RCCL did not return (SD_BENCH_RCCL_TIMEOUT)"
+                line["config"]["library_path"] = {"status": "timeout: the library's communication path did not return (SD_BENCH_RCCL_TIMEOUT)",
+                                                  "python_path_ms_per_step": line["ms_per_step"]}
                 print(json.dumps(line), flush=True)
-        c_rccl = c_rccl_path(pkg, op, src, dst, args.steps, dist, backend, dev, rank, all_ok, on_timeout)
+
+        def library_leg():
+            info = {}
+            try:
+                op.comm(dev)
+                info["communicator"] = op.comm_kind
+                if op.comm_note:
+                    info["note"] = op.comm_note
+                ref = torch.empty_like(dst)
+                op.apply(ref, src)
+                op.apply_lib(dst, src)
+                torch.cuda.synchronize()
+                same = bool(torch.equal(ref, dst))
+                del ref
+                if not all_ok(same):
+                    info["status"] = "ran, but its result differs from the Python-issued step: not timed"
+                    return info, None
+                el, _ev, st, _s, _d = timed(lambda d, s_: op.apply_lib(d, s_), src, dst)
+                info["status"] = "ok: bit-identical to the Python-issued step"
+                info["ms_per_step"] = el / args.steps * 1e3
+                return info, (el, st)
+            except Exception as e:     # noqa: BLE001 -- a failed leg is reported, the Python-issued headline stays
+                info["status"] = "failed: %r" % (e,)
+                all_ok(False)
+                return info, None
+        info, res = with_watchdog(library_leg, rank, on_timeout)
         if rank == 0:
-            line["config"]["c_rccl_path_ms"] = c_rccl
+            info["python_path_ms_per_step"] = line["ms_per_step"]
+            if res is not None:
+                line = build_line(res[0], res[1], "library: sd_apply_sharded on the %s communicator" % (
+                    "library's RCCL" if info.get("communicator") == "rccl" else "torch.distributed callback"), info)
+            else:
+                line["config"]["library_path"] = info
     if rank == 0:
         if world == 1 and not args.no_cpu:
             try:

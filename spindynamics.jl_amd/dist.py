@@ -254,6 +254,7 @@ class ShardedOperator:
         self.recv_slabs, self.send_slabs = model.shard_slabs()
         self._halo = {}
         self._comm = None
+        self.comm_kind, self.comm_note = None, ""     # which communicator comm() settled on ("rccl" / "torch"), and why not RCCL
         self._routes = None               # two-hop routes of the halo messages (SD_RELAY=1, popcount-cell ownership, >= 3 ranks)
 
     def relay_plan(self, group=None):
@@ -280,17 +281,57 @@ class ShardedOperator:
         return self._routes or None
 
     def comm(self, device, group=None):
-        """The communicator handed to the C recursion-level entry points: RCCL itself with SD_COMM=rccl, else
-        torch.distributed behind callbacks (None for a single rank)."""
+        """The communicator handed to the C recursion-level entry points (None for a single rank).
+
+        Default (SD_COMM unset or "auto"): with an NCCL (= RCCL) process group the library's OWN RCCL communicator -- grouped
+        ncclSend/ncclRecv beside the interior tiles and ncclAllReduce of the device scalars, queued on HIP streams by the C
+        side, a recursion step never touches the host -- once every rank has created it and passed its self-test (an all-reduce
+        and a ring send/receive, csrc/comm.cpp); otherwise, and for any other backend (gloo rehearsals), torch.distributed
+        behind the callback communicator, which costs one host round trip per reduction.  The ranks agree on the outcome, so
+        all of them take the same path; `self.comm_kind` says which ("rccl" / "torch"), `self.comm_note` why a fallback happened.
+        SD_COMM=torch forces the callbacks, SD_COMM=rccl makes a failure of the RCCL path an error instead of a fallback."""
         import os
         if self.world == 1:
             return None
         if self._exchange_fn is not None:
             raise _lib.ArgumentError("virtual shards (one process) cover single applies only: the recursions need real ranks")
         if self._comm is None:
-            kind = os.environ.get("SD_COMM", "torch")
-            self._comm = RcclComm(self, device, group) if kind == "rccl" else TorchComm(self, device, group)
+            import torch
+            import torch.distributed as dist
+            kind = os.environ.get("SD_COMM", "auto")
+            backend = dist.get_backend(group)
+            self.comm_kind, self.comm_note = None, ""
+            if kind == "rccl" or (kind == "auto" and backend == "nccl"):
+                cm, ok = None, False
+                try:
+                    cm = RcclComm(self, device, group)
+                    m = self.model
+                    m.ctx.set_stream(torch.cuda.current_stream(device).cuda_stream)
+                    check(lib().sd_comm_selftest(m.ctx.h, cm.h), m.ctx.h)
+                    ok = True
+                except Exception as e:          # noqa: BLE001 -- agreed on below: every rank falls back together
+                    self.comm_note = "rank %d: the library's RCCL communicator failed (%r)" % (self.rank, e)
+                t = torch.tensor([1.0 if ok else 0.0], device=device if backend == "nccl" else "cpu")
+                dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+                if float(t.item()) == 1.0:
+                    self._comm, self.comm_kind = cm, "rccl"
+                else:
+                    if cm is not None:
+                        cm.close()
+                    if not self.comm_note:
+                        self.comm_note = "another rank's RCCL communicator failed its self-test"
+                    if kind == "rccl":
+                        raise _lib.SpinDynError(_lib.SD_ECOMM, self.comm_note)
+            if self._comm is None:
+                self._comm, self.comm_kind = TorchComm(self, device, group), "torch"
         return self._comm
+
+    def apply_lib(self, out, psi, group=None, overlap=True):
+        """out = H psi on the owned rows through the library's own sharded entry point sd_apply_sharded (pack, halo exchange on the
+        communicator of comm(), interior tiles beside it, boundary tiles after it) -- the step every sharded recursion runs."""
+        code = _lib.SD_C128 if psi.is_complex() else _lib.SD_F64
+        self._call(lib().sd_apply_sharded, psi, code, out.data_ptr(), psi.data_ptr(), self.n_local, 1 if overlap else 0, group=group)
+        return out
 
     def _call(self, fn, x, *args, group=None):
         """Run a sd_*_sharded entry point on the stream torch is using for x's device."""
