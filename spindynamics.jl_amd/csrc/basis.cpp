@@ -366,6 +366,10 @@ int sd_build_plan(sd_model *m, int rank, int nranks, std::string &err) {
     while (LS > 2 && longest(LS) > 4096) --LS;
   }
   int p = L - LS;
+  m->max_tile_len_all = 0;
+  if (m->nup >= 0)
+    for (int t = std::max(0, m->nup - (L - LS)); t <= std::min(LS, m->nup); ++t)
+      m->max_tile_len_all = std::max<int>(m->max_tile_len_all, (int)std::min<int64_t>(B(m, LS, t), 1 << 30));
   if (m->nup < 0 || p > SD_MAX_PREFIX_BITS) {
     // generic (untiled) path: per-row rank/unrank on device
     m->p = -1; m->LS = 0;
@@ -426,6 +430,7 @@ int sd_build_plan(sd_model *m, int rank, int nranks, std::string &err) {
   m->suf_off[LS + 1] = (int32_t)m->suf_states.size();
   // packed partner table of the suffix bonds (sd_dev_model::suf_part): 10-bit fields hold partner row + 1 <= C(12,6) = 924
   m->suf_part.clear(); m->suf_dg.clear();
+  m->wrap_hop = -1;
   if (LS <= 12) {
     m->suf_part.assign(4 * m->suf_states.size(), 0u);
     m->suf_dg.assign(m->suf_states.size(), 0);
@@ -438,9 +443,26 @@ int sd_build_plan(sd_model *m, int rank, int nranks, std::string &err) {
           const uint32_t partner = (uint32_t)m->suf_rank[sg ^ (3u << (a - 1))] + 1u;     // same sector: same popcount
           w[(a - 1) / 3] |= partner << (10 * ((a - 1) % 3));
         }
-      w[3] |= (uint32_t)__builtin_popcount((sg ^ (sg >> 1)) & inner) << 20;
-      w[3] |= (sg & 1u) << 30;
       m->suf_dg[k] = (uint8_t)(__builtin_popcount((sg ^ (sg >> 1)) & inner) | ((sg & 1u) << 4));
+    }
+    // the first general bond, if it joins a prefix and a suffix site (sd_dev_model::wrap_hop)
+    m->wrap_hop = -1;
+    const int nnh = count_nn_hops(m);
+    if (nnh > 0 && nnh < (int)m->hop_i.size() && p >= 1) {
+      const int bi = m->hop_i[nnh] - 1, bj = m->hop_j[nnh] - 1;
+      if ((bi < p) != (bj < p)) {
+        const int sb = (bi < p ? bj : bi) - p;
+        m->wrap_hop = nnh; m->wrap_pb = bi < p ? bi : bj;
+        for (int t = 0; t <= LS; ++t)
+          for (int32_t i = m->suf_off[t]; i < m->suf_off[t + 1]; ++i) {
+            const uint32_t sg = m->suf_states[i];
+            const bool up = (sg >> sb) & 1u;
+            const int tq = up ? t - 1 : t + 1;
+            uint32_t field = 0;
+            if (tq >= 0 && tq <= LS) field = (uint32_t)m->suf_rank[sg ^ (1u << sb)] + 1u;    // rank inside sector tq
+            m->suf_part[4 * (size_t)i + 3] |= (field << 20) | ((up ? 1u : 0u) << 30);
+          }
+      }
     }
   }
 
@@ -788,6 +810,8 @@ int sd_upload_model(sd_model *m, std::string &err) {
       if ((rc = up(m, m->suf_part, &d.suf_part, err))) return rc;
       if ((rc = up(m, m->suf_dg, &d.suf_dg, err))) return rc;
     } else { d.suf_part = nullptr; d.suf_dg = nullptr; }
+    d.wrap_hop = m->suf_part.empty() ? -1 : m->wrap_hop; d.wrap_pb = m->wrap_pb;
+    if (getenv("SD_NO_WRAP_IMAGE")) d.wrap_hop = -1;      // A/B: the gather form of the wrap bond
     if ((rc = up(m, m->tile_gbase, &d.tile_gbase, err))) return rc;
     d.n_pack = (int)m->pack_len.size();
     if ((rc = up(m, m->pack_src, &d.pack_src, err))) return rc;

@@ -91,6 +91,7 @@ __global__ __launch_bounds__(BLOCK, (NC == 2 ? SD_LB_C128 : SD_LB_F64)) void k_a
   V *tile = reinterpret_cast<V *>(smem);                       // row 0: all zero; rows 1..len: the tile's psi
   int *lbin = reinterpret_cast<int *>(smem + (size_t)(max_len + 1) * sizeof(V));   // !PK only
   double *red = reinterpret_cast<double *>(lbin + 16 * SD_BIN_STRIDE);
+  V *tile2 = reinterpret_cast<V *>(red + 32);                  // wrap bond (dm.wrap_hop): row 0 zero, rows 1.. the partner tile
 
   if (ea.batch > 1) {                                          // vector blockIdx.y of a batch (sd_epi_args::batch)
     const int64_t boff = (int64_t)blockIdx.y * ea.bstride * NC;      // in doubles
@@ -300,6 +301,33 @@ __global__ __launch_bounds__(BLOCK, (NC == 2 ? SD_LB_C128 : SD_LB_F64)) void k_a
 #pragma unroll
     for (int r = 0; r < R; ++r) pt[PK ? r : 0] = __builtin_amdgcn_raw_buffer_load_b128(rp, (uint32_t)i0 * 16u + (uint32_t)(r * 64) * 16u, 0, 0);
   }
+  // Wrap bond (the first general bond, one site in the prefix and one in the suffix: the periodic chain's (L, 1)).  Its partner
+  // rows are scattered over the whole of ONE tile, P ^ (1 << wrap_pb) -- as a per-row gather every fetched line is half used and the
+  // address unit pays per line (+19 % on the apply).  The partner tile is streamed instead, coalesced like a far bond, into a
+  // second LDS image (the stream registers are free now) and read there after the suffix bonds, at the row the packed table names.
+  // (not for the 8-row Float64 form: its 96 registers -- five waves -- have no room, the code would spill; it keeps the gather)
+  const bool wrap = PK && !(NC == 1 && R == 8) && nn > 0 && dm.wrap_hop == nn;
+  bool wrap_on = false;
+  if (wrap) {
+    const uint32_t Q = P ^ (1u << dm.wrap_pb);
+    const int t2q = dm.nup - __popc(Q);
+    if (t2q >= 0 && t2q <= LS) {
+      wrap_on = true;
+      const int64_t qb = dm.addr[Q];
+      const int lenq = (int)dm.binom[LS * (SD_MAX_L + 1) + t2q];
+      const V *__restrict__ pbq = (halo && qb >= dm.n_local) ? halo + (qb - dm.n_local) : psi + qb;
+      const __amdgpu_buffer_rsrc_t rq = make_rsrc(pbq, (uint32_t)lenq * ES);
+      // (the partner tile belongs to the suffix sector t' +- 1: it may be longer than the BLOCK * R rows this workgroup covers)
+      for (int c0 = 0; c0 < lenq; c0 += BLOCK * R) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) buf_load(va[r], rq, off0 + (uint32_t)(c0 + r * 64) * ES);
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+          if (c0 + i0 + r * 64 < lenq) tile2[1 + c0 + i0 + r * 64] = va[r];
+      }
+      if (tid == 0) tile2[0] = V{};
+    }
+  }
   SD_STAMP(4);
 
   // ---- general bonds (anything after the leading chain bonds: the periodic (L,1) bond, long-range lists) ----
@@ -398,11 +426,29 @@ __global__ __launch_bounds__(BLOCK, (NC == 2 ? SD_LB_C128 : SD_LB_F64)) void k_a
     }
   }
   // ---- the general bonds in list order ----
-  if (have_g) {
-    if (PK) request_g0();
+  if (wrap) {
+    __syncthreads();                                     // the second image is complete (every wave takes this branch or none)
+    if (wrap_on) {
+      const double Jw = dm.hop_J[nn];
+      const uint32_t bpb = (P >> dm.wrap_pb) & 1u;
+      const unsigned char *tb2 = reinterpret_cast<const unsigned char *>(tile2);
+      constexpr uint32_t SH = NC == 2 ? 4 : 3;
 #pragma unroll
-    for (int r = 0; r < R; ++r)
-      if (gflip(g0, r)) acc[r] = accum<false>(acc[r], gJ, va[r]);   // rows without the hop keep acc untouched
+      for (int r = 0; r < R; ++r) {                      // (row by row: a batch of R values would cost the Float64 form a register spill)
+        const uint32_t w3 = pt[PK ? r : 0].w;
+        const bool has = ((w3 >> 30) & 1u) != bpb;       // the row's suffix site differs from the tile's prefix site
+        const uint32_t ad = has ? (((w3 >> 20) & 0x3FFu) << SH) : 0u;
+        acc[r] = accum<false>(acc[r], Jw, *reinterpret_cast<const V *>(tb2 + ad));     // (rows without the hop add J * 0)
+      }
+    }
+  }
+  if (have_g) {
+    if (!wrap) {
+      if (PK) request_g0();
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+        if (gflip(g0, r)) acc[r] = accum<false>(acc[r], gJ, va[r]);   // rows without the hop keep acc untouched
+    }
     for (int h = nn + 1; h < dm.n_hop; ++h) {
       const GBond g = gbond(h);
       if (g.kind < 0) continue;
@@ -804,6 +850,8 @@ int sd_launch_apply(sd_ctx *ctx, const sd_model *m, int dtype, void *out, const 
         const int cls = m->seg_cls[sg];
         const int seg_max = std::min(max_len, (64 << cls) * 4);
         size_t shmem = (size_t)(seg_max + 1) * esz + 16 * SD_BIN_STRIDE * sizeof(int) + 32 * sizeof(double) + 16;
+        if (dm.wrap_hop >= 0 && dm.wrap_hop == dm.nn_hops) shmem += (size_t)(m->max_tile_len_all + 1) * esz;   // the wrap bond's partner tile: any length class, owned or imported
+        // (the 8-row Float64 form does not use it: launch_tiled; asking for it there would only cost occupancy -- but it is 7.4 KB)
         {   // experiment knob: SD_LDS_MIN_KB_<cls> raises the LDS request of a class, i.e. lowers its workgroups per CU
           static int min_kb[SD_N_LEN_CLASS] = {-1, -1, -1, -1, -1};
           if (min_kb[cls] < 0) {

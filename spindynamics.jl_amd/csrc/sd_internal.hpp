@@ -120,6 +120,11 @@ struct sd_dev_model {
   // diagonal needs no configuration at all.  Null for LS > 12 (k_apply_tiled then computes partners from binomials).
   const uint32_t *suf_part;
   const uint8_t *suf_dg;         // per row of every suffix sector: anti-parallel pairs inside the suffix (bits 0..3), first suffix site (bit 4); with suf_part
+  // First general bond of the hop list when it joins a prefix site and a suffix site (the periodic chain's (L, 1)): every partner
+  // row lies in the ONE tile P ^ (1 << wrap_pb).  suf_part's word 3 then holds, in bits 20..29, 1 + the partner's row inside that
+  // tile (suffix sector t' + 1 when the row's suffix site is down, t' - 1 when it is up) and in bit 30 the row's suffix site; the
+  // kernel streams the partner tile into a second LDS image and reads it there.  wrap_hop = index of that hop, or -1.
+  int wrap_hop, wrap_pb;
   int need_sig;                  // the kernel must load the rows' suffix configurations (general bonds, or a diagonal that is not the uniform chain form / cached)
   const int64_t *far_base;       // per processed tile (single_rec order) p entries: base of the partner tile for prefix bond b = lane+1 and, in entry p-1, of the straddling bond's partner rows; -1: no hop
   int n_singles;
@@ -155,6 +160,7 @@ struct sd_model {
   std::vector<uint16_t> suf_states, suf_rank;
   std::vector<uint32_t> suf_part;   // packed suffix-bond partner table (see sd_dev_model), empty for LS > 12
   std::vector<uint8_t> suf_dg;
+  int wrap_hop = -1, wrap_pb = 0;   // see sd_dev_model
   std::vector<int64_t> far_base;
   std::vector<int32_t> suf_off;
   std::vector<sd_slab> recv_slabs, send_slabs;
@@ -169,7 +175,8 @@ struct sd_model {
   int seg_cls[2 * SD_N_LEN_CLASS] = {0};       // workgroup size of a segment's kernel = 64 << seg_cls
   std::vector<int64_t> single_base;
   std::vector<sd_tile_rec> single_rec;
-  int max_tile_len = 0;
+  int max_tile_len = 0;        // longest OWNED tile
+  int max_tile_len_all = 0;    // longest tile of the whole basis (a partner tile imported from a peer may be longer than any owned one)
   bool hop_pow2 = false;  // every NN hop amplitude is +-2^k (or 0): J*psi is exact, fma == mul+add
   // device copies
   sd_dev_model dm{};
