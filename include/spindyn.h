@@ -297,6 +297,9 @@ typedef struct sd_shard_info {
   int64_t n_local_tiles;
   int64_t n_pack;           /* entries of the pack list (mode 1) */
   int64_t n_interior_tiles; /* tiles whose hop partners are all owned (sd_apply_sharded_dev part 1) */
+  int64_t n_interior_rows;  /* rows of those tiles (the rest of n_local waits for the halo) */
+  int64_t packed;           /* mode 1: 1 = the send slabs index the packed send buffer (sd_shard_pack_dev, n_send elements); 0 = they index the
+                               vector itself -- the tiles a peer needs form long contiguous runs, one slab per run, no pack, no send buffer */
 } sd_shard_info;
 typedef struct sd_slab {
   int peer;                 /* rank on the other side */

@@ -18,7 +18,10 @@ for rank in [int(r) for r in sys.argv[3:]]:
     op.fill_randn(a, 1)
     halo = op.halo(a)
     halo.fill_(0.5)
-    res = {"L": L, "world": world, "rank": rank, "n_local": op.n_local, "n_halo": op.n_halo, "N": model.N}
+    info = model.shard_info()
+    res = {"L": L, "world": world, "rank": rank, "n_local": op.n_local, "n_halo": op.n_halo, "N": model.N,
+           "n_interior_rows": int(info.n_interior_rows), "n_boundary_rows": op.n_local - int(info.n_interior_rows),
+           "n_interior_tiles": int(info.n_interior_tiles), "mode": op.mode}
     for name, part in (("all", 0), ("interior", 1), ("boundary", 2)):
         for _ in range(2):
             op._launch(b, a, halo, 0, part=part)
@@ -30,7 +33,7 @@ for rank in [int(r) for r in sys.argv[3:]]:
         torch.cuda.synchronize()
         res[name + "_ms"] = e0.elapsed_time(e1) / 5
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    if op.mode == "class":
+    if op.packed:
         op.pack(a)
         e0.record()
         for _ in range(5):
@@ -39,6 +42,9 @@ for rank in [int(r) for r in sys.argv[3:]]:
         torch.cuda.synchronize()
         res["pack_ms"] = e0.elapsed_time(e1) / 5
         res["n_send"] = op.n_send
+        res["packed"] = int(info.packed)
+    res["local_total_ms"] = res["interior_ms"] + res["boundary_ms"] + res.get("pack_ms", 0.0)
+    res["ideal_ms_at_single_gpu_rate"] = None
     print(json.dumps(res), flush=True)
     del a, b, halo, op, model
     torch.cuda.empty_cache()

@@ -39,7 +39,7 @@ class sd_shard_info(C.Structure):
     _fields_ = [("rank", C.c_int), ("nranks", C.c_int), ("row_lo", C.c_int64), ("row_hi", C.c_int64),
                 ("n_local", C.c_int64), ("n_halo", C.c_int64), ("n_recv_slabs", C.c_int64),
                 ("n_send_slabs", C.c_int64), ("mode", C.c_int), ("n_send", C.c_int64), ("n_local_tiles", C.c_int64), ("n_pack", C.c_int64),
-                ("n_interior_tiles", C.c_int64)]
+                ("n_interior_tiles", C.c_int64), ("n_interior_rows", C.c_int64), ("packed", C.c_int64)]
 
 
 class sd_slab(C.Structure):

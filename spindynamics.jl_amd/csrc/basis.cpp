@@ -549,6 +549,68 @@ int sd_build_plan(sd_model *m, int rank, int nranks, std::string &err) {
         }
         owner[k] = bisect_owner(bis, cnt);
       }
+      // Balance.  A threshold on an integer count can only cut between two counts, and the cell at the median holds 15-20 % of a
+      // branch: the ranks came out at 62-85 M rows where 75 M is even (L=32, 8 ranks).  Finer: order the configurations of a
+      // branch by (count of the block, then the K sites that follow it, read as a binary number) and cut THAT order at its
+      // weighted median.  The bonds inside those K sites now cross the cut too, but each with a fraction of the rows that sat at
+      // the integer threshold: at L=32, 8 ranks the import is unchanged (333 M rows in all, busiest pair 17.8 M) and the ranks
+      // own 71.2-77.4 M rows (K = 3).  Kept only if it does not cross more bonds (x 1.05) than the integer cut.
+      int K = 3;
+      if (const char *e = getenv("SD_SHARD_FINE")) K = std::max(0, std::min(6, atoi(e)));
+      if (K > 0) {
+        std::vector<int> fine(T, 0);
+        std::vector<int32_t> idx_of((size_t)nP, -1);
+        for (size_t k = 0; k < T; ++k) idx_of[tiles[k].P] = (int32_t)k;
+        for (int lev = 0; lev < bis.d; ++lev) {
+          const int sb = bis.s[bis.d - lev], kk = std::min(K, p - sb);
+          const uint32_t bmask = (1u << sb) - 1u;
+          auto zof = [&](uint32_t P) {
+            uint32_t z = (uint32_t)__builtin_popcount(P & bmask);
+            for (int j = 0; j < kk; ++j) z = 2 * z + ((P >> (sb + j)) & 1u);
+            return z;
+          };
+          const size_t nz = ((size_t)sb + 1) << kk;
+          std::vector<double> hist((size_t)(1 << lev) * nz, 0.0);
+          for (size_t k = 0; k < T; ++k) hist[(size_t)fine[k] * nz + zof(tiles[k].P)] += (double)tlen[k];
+          std::vector<uint32_t> thr((size_t)1 << lev, 0);
+          for (int pre = 0; pre < (1 << lev); ++pre) {
+            const double *h = hist.data() + (size_t)pre * nz;
+            double tot = 0; for (size_t z = 0; z < nz; ++z) tot += h[z];
+            double acc = 0, bestd = 1e300;
+            for (size_t z = 0; z + 1 < nz; ++z) {
+              acc += h[z];
+              const double dd = std::fabs(acc - tot / 2);
+              if (dd < bestd) { bestd = dd; thr[pre] = (uint32_t)z; }
+            }
+          }
+          for (size_t k = 0; k < T; ++k) fine[k] = 2 * fine[k] + (zof(tiles[k].P) > thr[fine[k]] ? 1 : 0);
+        }
+        // rows whose hop partner lives on another rank (partner tiles counted once per reading tile), largest rank
+        auto judge = [&](const std::vector<int> &own, double &crossing, double &largest) {
+          crossing = 0;
+          std::vector<double> size(nranks, 0.0);
+          for (size_t k = 0; k < T; ++k) {
+            const uint32_t P = tiles[k].P;
+            size[own[k]] += (double)tlen[k];
+            for (int b = 1; b <= p - 1; ++b)
+              if (((P >> (b - 1)) ^ (P >> b)) & 1u) {
+                const int32_t j = idx_of[P ^ (3u << (b - 1))];
+                if (j >= 0 && own[j] != own[k]) crossing += (double)tlen[j];
+              }
+          }
+          largest = 0;
+          bool empty = false;
+          for (double v : size) { largest = std::max(largest, v); if (v <= 0) empty = true; }
+          return !empty;
+        };
+        double c0 = 0, l0 = 0, c1 = 0, l1 = 0;
+        judge(owner, c0, l0);
+        const bool ok1 = judge(fine, c1, l1);
+        if (getenv("SD_SHARD_DEBUG"))
+          fprintf(stderr, "[sd shard] fine thresholds (K=%d): largest rank %.3g -> %.3g rows, crossing rows %.4g -> %.4g: %s\n", K, l0, l1, c0,
+                  c1, (ok1 && l1 < l0 && c1 <= 1.05 * c0) ? "kept" : "dropped");
+        if (ok1 && l1 < l0 && c1 <= 1.05 * c0) owner.swap(fine);
+      }
     } else if (bm1 < 0) mode = 0;
     else {
       const uint32_t mA = (1u << bm1) - 1, mB = (1u << bm2) - 1;
@@ -591,11 +653,20 @@ int sd_build_plan(sd_model *m, int rank, int nranks, std::string &err) {
   m->single_prefix = m->tile_prefix; m->single_base = m->tile_base;
 
   m->pack_src.clear(); m->pack_dst.clear(); m->pack_len.clear(); m->n_send = 0;
+  m->packed = 0;
   if (nranks > 1) {
     const int nn = count_nn_hops(m);
     std::vector<uint8_t> need(nP);
     std::vector<int64_t> nloc(nranks, 0);
-    for (size_t k = 0; k < T; ++k) nloc[owner[k]] += tlen[k];
+    // offset of every tile inside its OWNER's vector (owned tiles are stored compactly in natural order)
+    std::vector<int64_t> loc_all(T, 0);
+    for (size_t k = 0; k < T; ++k) { loc_all[k] = nloc[owner[k]]; nloc[owner[k]] += tlen[k]; }
+    // cells: the tiles a peer needs come in runs that are contiguous in the owner's vector (at L=28, 8 ranks: ~50 runs of
+    // ~80 000 rows per rank, 16x longer at L=32).  Such runs travel straight from psi -- one send per run, matched in order by
+    // one receive per run -- and the pack kernel and its send buffer disappear (round 3: 0.16-0.39 ms per step and rank at
+    // L=32).  Only plans whose runs are short on average (< 2048 rows) keep the packed form; SD_SHARD_PACK=1 / 0 forces / forbids it.
+    std::vector<sd_slab> d_recv, d_send;          // the direct form, built beside the packed one; chosen after the loop
+    int64_t n_runs_all = 0, n_rows_all = 0;
     for (int q = 0; q < nranks; ++q) {
       std::fill(need.begin(), need.end(), 0);
       collect_needs(m, tiles, owner, q, nn, need);
@@ -631,12 +702,23 @@ int sd_build_plan(sd_model *m, int rank, int nranks, std::string &err) {
           if (o == q) continue;
           const int64_t start = halo_off, sstart = m->n_send;
           int64_t count = 0;
+          int64_t run_loc = -1, run_halo = 0, run_cnt = 0;       // current run: offset at the owner, offset at the receiver, rows
+          auto flush_run = [&]() {
+            if (run_cnt <= 0) return;
+            ++n_runs_all; n_rows_all += run_cnt;
+            if (q == rank) d_recv.push_back({o, run_halo, run_cnt, -1});
+            if (o == rank) d_send.push_back({q, run_loc, run_cnt, -1});
+            run_cnt = 0;
+          };
           for (size_t k = 0; k < T; ++k) {
             if (owner[k] != o || !need[tiles[k].P]) continue;
             if (q == rank) m->addr[tiles[k].P] = halo_off;
             if (o == rank) { m->pack_src.push_back(local_of[k]); m->pack_dst.push_back(m->n_send); m->pack_len.push_back((int32_t)tlen[k]); m->n_send += tlen[k]; }
+            if (run_cnt > 0 && loc_all[k] == run_loc + run_cnt) run_cnt += tlen[k];
+            else { flush_run(); run_loc = loc_all[k]; run_halo = halo_off; run_cnt = tlen[k]; }
             halo_off += tlen[k]; count += tlen[k];
           }
+          flush_run();
           if (count > 0) {
             if (q == rank) m->recv_slabs.push_back({o, start, count, -1});
             if (o == rank) m->send_slabs.push_back({q, sstart, count, -1});
@@ -644,6 +726,14 @@ int sd_build_plan(sd_model *m, int rank, int nranks, std::string &err) {
         }
       }
       if (q == rank) m->n_halo = halo_off - m->n_local;
+    }
+    if (mode == 1) {
+      const char *fp = getenv("SD_SHARD_PACK");         // unset: by run length; 1: always pack; 0: never (tests)
+      const bool direct = fp ? atoi(fp) == 0 : (n_runs_all > 0 && n_rows_all / n_runs_all >= 2048);
+      if (direct) {          // the same on every rank: the statistics cover all (owner, receiver) pairs
+        m->recv_slabs.swap(d_recv); m->send_slabs.swap(d_send);
+        m->pack_src.clear(); m->pack_dst.clear(); m->pack_len.clear(); m->n_send = 0;
+      } else m->packed = 1;
     }
   }
   // Launch segments of the single tiles: (interior | boundary) x (length class).  Interior tiles (every hop partner owned)

@@ -382,6 +382,11 @@ int sd_model_shard_info(const sd_model *m, sd_shard_info *out) {
   out->mode = m->shard_mode; out->n_send = m->n_send; out->n_local_tiles = (int64_t)m->tile_prefix.size();
   out->n_pack = (int64_t)m->pack_len.size();
   out->n_interior_tiles = m->n_interior;
+  out->n_interior_rows = 0;
+  if (m->p >= 0)
+    for (int k = 0; k < m->n_interior && k < (int)m->single_prefix.size(); ++k)
+      out->n_interior_rows += sd_binom(m->LS, m->nup - __builtin_popcount(m->single_prefix[k]));
+  out->packed = m->packed;
   return SD_OK;
 }
 

@@ -107,7 +107,7 @@ struct Op {
     n = m->n_local;
     if (m->nranks > 1) {
       RC(halo.alloc(ctx, 2 * std::max<int64_t>(m->n_halo, 1)));
-      if (m->shard_mode == 1) RC(send.alloc(ctx, 2 * std::max<int64_t>(m->n_send, 1)));
+      if (m->packed) RC(send.alloc(ctx, 2 * std::max<int64_t>(m->n_send, 1)));
     }
     return SD_OK;
   }
@@ -118,7 +118,7 @@ struct Op {
     if (m->nranks == 1) return sd_launch_apply(ctx, m, dtype, out, psi, epi, ea, 0);
     ea.halo = halo.p;
     const void *src = psi;
-    if (m->shard_mode == 1) { RC(sd_launch_pack(ctx, m, dtype, psi, send.p)); src = send.p; }
+    if (m->packed) { RC(sd_launch_pack(ctx, m, dtype, psi, send.p)); src = send.p; }
     RC(sd_comm_exchange_start(ctx, comm, m, dtype, src, halo.p));
     if (overlap && m->n_interior > 0 && n > 0) {
       RC(sd_launch_apply(ctx, m, dtype, out, psi, epi, ea, 1));

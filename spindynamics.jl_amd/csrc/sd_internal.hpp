@@ -166,6 +166,8 @@ struct sd_model {
   std::vector<sd_slab> recv_slabs, send_slabs;
   int shard_mode_req = -1;       // -1 auto (env SD_SHARD_MODE), 0 index ranges, 1 popcount cells
   int shard_mode = 0;           // mode in effect
+  int packed = 0;               // cell mode: 1 = the peers' tiles are gathered into a send buffer by the pack kernel (short runs); 0 = the
+                                // send slabs index psi itself (contiguous runs; also index-range mode and the full basis)
   int64_t n_send = 0;           // elements of the packed send buffer (cell mode)
   std::vector<int64_t> pack_src, pack_dst, tile_gbase;
   std::vector<int32_t> pack_len;

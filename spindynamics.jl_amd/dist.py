@@ -151,7 +151,7 @@ class TorchComm:
             import torch.distributed as dist
             op = self.op
             per = 2 if dtype == _lib.SD_C128 else 1
-            n_src = op.n_send if op.mode == "class" else op.n_local
+            n_src = op.n_send if op.packed else op.n_local
             src = _dev_tensor(src_ptr, max(n_src, 1) * per, self.device)
             dst = _dev_tensor(halo_ptr, max(op.n_halo, 1) * per, self.device)
             staged = self.backend == "gloo"
@@ -245,6 +245,7 @@ class ShardedOperator:
         model.set_shard(rank, world, mode)
         info = model.shard_info()
         self.mode = "class" if int(info.mode) == 1 else "range"
+        self.packed = bool(int(info.packed))   # the send slabs index the packed send buffer (short runs) instead of the vector itself
         self.n_send = int(info.n_send)
         self._send = {}
         self.overlap = True               # run interior tiles while the halo exchange is in flight
@@ -263,7 +264,7 @@ class ShardedOperator:
         import os
         if self._routes is None:
             self._routes = False
-            if os.environ.get("SD_RELAY", "0") not in ("", "0") and self.mode == "class" and self.world >= 3 \
+            if os.environ.get("SD_RELAY", "0") not in ("", "0") and self.packed and self.world >= 3 \
                     and self._exchange_fn is None:
                 import torch.distributed as dist
                 mine = [(int(peer), int(cnt)) for (peer, off, cnt, _g) in self.recv_slabs]
@@ -394,7 +395,7 @@ class ShardedOperator:
             return halo, []
         import torch
         import torch.distributed as dist
-        out = self.pack(psi) if self.mode == "class" else psi     # what the send slabs index
+        out = self.pack(psi) if self.packed else psi     # what the send slabs index
         src = torch.view_as_real(out) if out.is_complex() else out
         dst = torch.view_as_real(halo) if halo.is_complex() else halo
         nl = self.n_local
@@ -475,7 +476,7 @@ class ShardedOperator:
         import torch
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(7)]
         ev[5].record()
-        if self.mode == "class" and self.world > 1 and self._exchange_fn is None:
+        if self.packed and self.world > 1 and self._exchange_fn is None:
             self.pack(psi)                       # timed alone; exchange_start packs the same bytes again
         ev[6].record()
         ev[0].record()

@@ -183,7 +183,14 @@ def imported_rows(models, slabs, r):
         lo -= int(info.n_local)
         if int(info.mode) == 0:
             out[lo:lo + cnt] = np.arange(g, g + cnt)
-        else:   # class mode: the peer packs its tiles in natural order; exactly one message per (peer, r) pair
+        elif not int(models[peer].shard_info().packed):
+            # class mode, contiguous runs: the k-th slab r receives from the peer is the k-th slab the peer sends to r, a run of
+            # the peer's own vector
+            k = [x for x in slabs[r][0] if x[0] == peer].index((peer, lo + int(info.n_local), cnt, g))
+            (_q, so, scnt, _g) = [x for x in slabs[peer][1] if x[0] == r][k]
+            assert scnt == cnt
+            out[lo:lo + cnt] = models[peer].local_rows()[so:so + cnt]
+        else:   # class mode, packed: the peer packs its tiles in natural order; exactly one message per (peer, r) pair
             rows = models[peer].local_rows()
             src, dst, ln = models[peer].pack_list()
             (soff, scnt), = [(o, c) for (q, o, c, _g) in slabs[peer][1] if q == r]
@@ -194,10 +201,13 @@ def imported_rows(models, slabs, r):
     return out
 
 
-@pytest.mark.parametrize("mode", ["range", "class"])
+@pytest.mark.parametrize("mode", ["range", "class", "class-direct"])
 @pytest.mark.parametrize("L,nup,P", [(12, 6, 2), (14, 7, 3), (16, 8, 2), (16, 8, 8), (18, 9, 4), (17, 5, 5)])
 def test_shard_plan_is_consistent(pkg, L, nup, P, mode, monkeypatch):
     monkeypatch.setenv("SD_SUFFIX_BITS", "6")      # many tiles even at small L
+    if mode == "class-direct":                     # the form large plans take: contiguous runs sent straight from the vector
+        monkeypatch.setenv("SD_SHARD_PACK", "0")
+        mode = "class"
     check_shard_plan(pkg, L, nup, P, mode, "open")
 
 
@@ -211,6 +221,9 @@ def test_shard_plan_random(pkg, seed, monkeypatch):
     nup = int(rng.integers(1, L))
     P = int(rng.integers(2, 9))
     monkeypatch.setenv("SD_SUFFIX_BITS", str(int(rng.integers(3, 11))))
+    pack = str(rng.choice(["auto", "0", "1"]))          # cell mode: packed send buffer, or runs of the vector itself
+    if pack != "auto":
+        monkeypatch.setenv("SD_SHARD_PACK", pack)
     check_shard_plan(pkg, L, nup, P, str(rng.choice(["range", "class"])), str(rng.choice(["open", "periodic"])))
 
 
@@ -243,9 +256,12 @@ def check_shard_plan(pkg, L, nup, P, mode, boundary):
             s_ = [c for (peer, _, c, _g) in send if peer == q]
             t_ = [c for (peer, _, c, _g) in slabs[q][0] if peer == r]
             assert s_ == t_
-        if int(infos[r].mode) == 1:
+        if int(infos[r].mode) == 1 and int(infos[r].packed):
             assert sum(c for (_, _, c, _g) in send) == infos[r].n_send
             assert all(len([1 for (peer, _, _, _g) in send if peer == q]) <= 1 for q in range(P))
+        if int(infos[r].mode) == 1 and not int(infos[r].packed):
+            assert infos[r].n_send == 0 and all(0 <= o and o + c <= infos[r].n_local for (_, o, c, _g) in send)   # runs of the vector itself
+        assert len({int(i.packed) for i in infos}) == 1                      # every rank made the same choice
     # every hop partner of every owned row is either owned or inside the halo
     full = pkg.XXZChain(L, nup=nup, ctx=None, boundary=boundary)
     st = full.states

@@ -25,7 +25,10 @@ def _worker(rank, world, port, L, nup, mode, q, relay=False):
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                           SD_SUFFIX_BITS="6")
         if relay:                                            # two-hop routes for every message, however small
-            os.environ.update(SD_RELAY="2", SD_RELAY_MIN="0", SD_RELAY_CHUNKS="4")
+            os.environ.update(SD_RELAY="2", SD_RELAY_MIN="0", SD_RELAY_CHUNKS="4", SD_SHARD_PACK="1")
+        if mode == "class-direct":                           # cell ownership, contiguous runs sent straight from the vector (large plans)
+            os.environ.update(SD_SHARD_PACK="0")
+            mode = "class"
         sys.path.insert(0, ROOT)
         import torch
         import torch.distributed as dist
@@ -73,7 +76,8 @@ def _worker(rank, world, port, L, nup, mode, q, relay=False):
         q.put((rank, False, repr(e) + traceback.format_exc(), 0, None, 0.0, 0))
 
 
-@pytest.mark.parametrize("world,L,nup,mode", [(2, 12, 6, "range"), (3, 13, 5, "range"), (2, 14, 7, "class"), (3, 14, 6, "class")])
+@pytest.mark.parametrize("world,L,nup,mode", [(2, 12, 6, "range"), (3, 13, 5, "range"), (2, 14, 7, "class"), (3, 14, 6, "class"),
+                                              (2, 14, 7, "class-direct"), (4, 15, 7, "class-direct")])
 def test_halo_exchange_gloo(world, L, nup, mode):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")

@@ -179,6 +179,8 @@ def ranks8(pkg, request, monkeypatch):
     from virtual_ranks import VirtualRanks          # tests/ is on sys.path (pytest rootdir conftest)
     L, mode = request.param
     monkeypatch.setenv("SD_SUFFIX_BITS", "9")           # 2^(L-9) prefix tiles: every rank owns many, most with imported partners
+    if mode == "class":
+        monkeypatch.setenv("SD_SHARD_PACK", "0" if L == 20 else "1")    # both forms of the cell-mode exchange (runs of psi / packed)
     vr = VirtualRanks(pkg, lambda ctx: pkg.XXZChain(L, nup=L // 2, ctx=ctx), 8, mode)
     assert all(op.n_local > 0 for op in vr.ops) and any(op.n_halo > 0 for op in vr.ops)
     yield L, mode, vr

@@ -30,6 +30,9 @@ def test_virtual_shards_random(pkg, seed, monkeypatch):
     P = int(rng.integers(2, 9))
     monkeypatch.setenv("SD_SUFFIX_BITS", str(int(rng.integers(4, 13))))
     monkeypatch.setenv("SD_LEN_CLASSES", str(int(rng.choice([1, 2]))))
+    pack = str(rng.choice(["auto", "0", "1"]))      # cell mode: packed send buffer or contiguous runs of the vector itself
+    if pack != "auto":
+        monkeypatch.setenv("SD_SHARD_PACK", pack)
     kw = {"Jxy": float(rng.choice([1.0, 0.7])), "Jz": float(rng.normal()), "hz": float(rng.choice([0.0, 0.3])),
           "boundary": str(rng.choice(["open", "periodic"]))}
     check_virtual_shards(pkg, L, nup, P, str(rng.choice(["range", "class"])), kw, need_interior=False)
@@ -59,7 +62,7 @@ def check_virtual_shards(pkg, L, nup, P, mode, kw, need_interior=True):
         op.halo(buf).fill_(float("nan"))
         ops.append(op); bufs.append(buf)
     # class mode: the owner packs the requested tiles with the HIP pack kernel, the send slabs index that buffer
-    outs = [op.pack(b) if op.mode == "class" else b for op, b in zip(ops, bufs)]
+    outs = [op.pack(b) if op.packed else b for op, b in zip(ops, bufs)]
     # emulate the grouped send/recv: k-th slab r->q pairs with the k-th slab q receives from r
     for q in range(P):
         hq = ops[q].halo(bufs[q])

@@ -67,7 +67,7 @@ class ThreadComm:
                     oq = sh.ops[q]
                     sends = [s for s in oq.send_slabs if s[0] == op.rank]
                     assert len(sends) == len(recvs)
-                    n_src = oq.n_send if oq.mode == "class" else oq.n_local
+                    n_src = oq.n_send if oq.packed else oq.n_local
                     src = _lib.dev_tensor(sh.src[q][0], n_src * per, self.device)
                     for (_p, so, cnt, _g), (_p2, ro, cnt2, _g2) in zip(sends, recvs):
                         assert cnt == cnt2
