@@ -57,20 +57,16 @@ for L in Ls:
                 print(f"| {r} | " + " | ".join(f"{M[r, q] / 1e9:.3f}" if M[r, q] else "·" for q in range(P)) + " |")
             print("", flush=True)
             if mode == "class" and P >= 3:
-                # the two-hop routing the exchange uses with SD_RELAY=1 (dist.relay_routes), rounds in sequence
+                # the two-hop routing the exchange uses with SD_RELAY=1 (dist.relay_routes): pipelined, so the busiest LINK counts
                 dmod = sys.modules[pkg.__name__ + ".dist"]
                 Mel = {(q, r): int(M[r, q] // ES) for r in range(P) for q in range(P) if M[r, q] > 0}
                 routes = dmod.relay_routes(Mel, 8, 65536)
-                l1, l2 = {}, {}
-                for (o, r), lst in routes.items():
-                    for (k, lo, hi) in lst:
-                        if k < 0:
-                            l1[(o, r)] = l1.get((o, r), 0) + hi - lo
-                        else:
-                            l1[(o, k)] = l1.get((o, k), 0) + hi - lo
-                            l2[(k, r)] = l2.get((k, r), 0) + hi - lo
-                b1, b2 = max(l1.values()) * ES / 1e9, max(l2.values(), default=0) * ES / 1e9
-                wire = (sum(l1.values()) + sum(l2.values())) / max(1, sum(Mel.values()))
-                print(f"two-hop relays (`SD_RELAY=1`, 8 pieces per message, rounds in sequence): busiest link {busiest / 1e9:.3f} GB -> "
-                      f"{b1:.3f} + {b2:.3f} = {b1 + b2:.3f} GB ({'kept direct: no gain' if b2 == 0 else f'{(1 - (b1 + b2) * 1e9 / busiest) * 100:.0f} % less'}); "
-                      f"bytes on the wire x{wire:.2f}\n", flush=True)
+                load = dmod.relay_link_loads(Mel, routes)
+                b = max(load.values()) * ES / 1e9
+                wire = sum(load.values()) / max(1, sum(Mel.values()))
+                relayed = any(k >= 0 for lst in routes.values() for (k, _u) in lst)
+                floor = max(max(M.sum(axis=1)), max(M.sum(axis=0))) / min(7, P - 1) / 1e9
+                print(f"two-hop relays (`SD_RELAY=1`, 8 routing units per message, pipelined in 4 batches): busiest link {busiest / 1e9:.3f} GB -> "
+                      f"{b:.3f} GB ({'kept direct: no gain' if not relayed else f'{(1 - b * 1e9 / busiest) * 100:.0f} % less'}; "
+                      f"{b / 77e9 * 1e3 * 1e9:.1f}-{b / 60e9 * 1e3 * 1e9:.1f} ms at 77-60 GB/s); bytes on the wire x{wire:.2f}; "
+                      f"floor if the busiest rank's traffic were spread evenly over its {min(7, P - 1)} links: {floor:.3f} GB\n", flush=True)

@@ -13,6 +13,7 @@ Two ownership modes (csrc/basis.cpp):
 Transport: torch.distributed P2P ops, i.e. RCCL over xGMI on GPUs (backend "nccl") and gloo in the CPU tests.
 """
 import ctypes as C
+import os
 
 from . import _lib
 from ._lib import check, lib
@@ -35,95 +36,163 @@ _dev_tensor = _lib.dev_tensor
 
 def relay_routes(M, chunks=8, min_elems=0, force=False):
     """Two-hop routing of halo messages through peers whose links would idle (opt-in, SD_RELAY=1).
-    M[(owner, receiver)] = elements of the pair's message.  Every message of at least min_elems elements is cut into `chunks`
-    pieces; each piece takes the path -- direct, or owner -> k -> receiver -- that keeps (busiest link of round 1) + (busiest
-    link of round 2) smallest, largest pieces first (the greedy of profiles/relay_sim.py; ties by rank index, so every rank
-    computes the same plan).  Rounds are sequential, so the plan is kept only if the two busiest links together carry less than
-    the busiest direct message; otherwise everything stays direct (force=True, SD_RELAY=2, keeps it regardless: tests).  Returns {(owner, receiver): [(via or -1, lo, hi), ...]}:
-    element ranges of the message, pieces of one path merged."""
+    M[(owner, receiver)] = elements of the pair's message.  xGMI is point to point: a pair's bytes ride ONE link, and the
+    busiest (owner, receiver) pair of a sharded apply carries two to three times the mean.  Every message of at least min_elems
+    elements is cut into `chunks` routing units; each unit takes the path -- direct, or owner -> k -> receiver -- that keeps the
+    BUSIEST LINK smallest, where a link's load is everything it carries on either hop: the exchange is pipelined (`_RelayExchange`:
+    the second hop of one slice travels while the first hop of the next is under way), so what bounds it is the most loaded link,
+    not the sum of two rounds.  Largest units first, ties by rank index: every rank computes the same plan.  The plan is kept only
+    if its busiest link carries less than 0.9 of the busiest direct message (force=True, SD_RELAY=2, keeps it regardless: tests).
+    Returns {(owner, receiver): [(via or -1, units), ...]} with the units of one path merged (they sum to the message's unit
+    count: `chunks`, or 1 for a message too small to split)."""
     ranks = sorted({a for pr in M for a in pr})
-    l1, l2 = {}, {}
-    pieces = []
+    load = {}
+    units = []
     for (o, r), n in M.items():
         c = chunks if n >= max(min_elems, chunks) else 1
         for k in range(c):
-            pieces.append((n * (k + 1) // c - n * k // c, o, r))
-    pieces.sort(key=lambda t: (-t[0], t[1], t[2]))
+            units.append((n * (k + 1) // c - n * k // c, o, r, c))
+    units.sort(key=lambda t: (-t[0], t[1], t[2]))
     count = {}
-    for sz, o, r in pieces:
+    for sz, o, r, c in units:
         if sz == 0:
             continue
-        m1, m2 = max(l1.values(), default=0), max(l2.values(), default=0)
-        best = (max(m1, l1.get((o, r), 0) + sz) + m2, l1.get((o, r), 0) + sz, -1)
-        if M[(o, r)] >= max(min_elems, chunks):
+        top = max(load.values(), default=0)
+        d = load.get((o, r), 0) + sz
+        best = (max(top, d), d, 0, -1)                      # (busiest link afterwards, this path's busiest link, hops - 1, via)
+        if c > 1:
             for k in ranks:
                 if k == o or k == r:
                     continue
-                a, b = l1.get((o, k), 0) + sz, l2.get((k, r), 0) + sz
-                cand = (max(m1, a) + max(m2, b), max(a, b), k)
-                if cand[:2] < best[:2]:
+                a, b = load.get((o, k), 0) + sz, load.get((k, r), 0) + sz
+                cand = (max(top, a, b), max(a, b), 1, k)
+                if cand[:3] < best[:3]:
                     best = cand
-        k = best[2]
+        k = best[3]
         if k < 0:
-            l1[(o, r)] = l1.get((o, r), 0) + sz
+            load[(o, r)] = load.get((o, r), 0) + sz
         else:
-            l1[(o, k)] = l1.get((o, k), 0) + sz
-            l2[(k, r)] = l2.get((k, r), 0) + sz
+            load[(o, k)] = load.get((o, k), 0) + sz
+            load[(k, r)] = load.get((k, r), 0) + sz
         count.setdefault((o, r), {})
-        count[(o, r)][k] = count[(o, r)].get(k, 0) + sz
-    if not force and max(l1.values(), default=0) + max(l2.values(), default=0) >= max(M.values(), default=0):
-        return {pr: [(-1, 0, n)] for pr, n in M.items() if n > 0}     # the two rounds together are no shorter than the busiest direct message
-    routes = {}
-    for pr, per_via in count.items():
-        lo, lst = 0, []
-        for k in sorted(per_via):
-            lst.append((k, lo, lo + per_via[k]))
-            lo += per_via[k]
-        assert lo == M[pr]
-        routes[pr] = lst
-    return routes
+        count[(o, r)][k] = count[(o, r)].get(k, 0) + 1
+    if not force and max(load.values(), default=0) >= 0.9 * max(M.values(), default=0):
+        return {pr: [(-1, 1)] for pr, n in M.items() if n > 0}         # not worth a second hop: everything direct
+    return {pr: [(k, per_via[k]) for k in sorted(per_via)] for pr, per_via in count.items()}
+
+
+def relay_link_loads(M, routes):
+    """{(a, b): elements link a -> b carries per exchange} under `routes` (both hops), for reports and tests."""
+    load = {}
+    for (o, r), lst in routes.items():
+        tot = sum(u for _k, u in lst)
+        lo = 0
+        for (k, u) in lst:
+            sz = M[(o, r)] * (lo + u) // tot - M[(o, r)] * lo // tot
+            lo += u
+            for link in (((o, r),) if k < 0 else ((o, k), (k, r))):
+                load[link] = load.get(link, 0) + sz
+    return load
 
 
 class _RelayExchange:
-    """One halo exchange over the routes of relay_routes: round 1 = direct pieces and first hops, round 2 = second hops out
-    of the relays' buffers.  Both sides of every pair post their operations in the same canonical order (sorted pairs, pieces
-    in route order), which is what matches messages between two ranks.  wait() completes round 1, posts and completes round 2."""
+    """One halo exchange over the routes of relay_routes, pipelined: every message is cut into `nb` slices, each slice into the
+    sub-ranges its paths carry (in proportion to their routing units); batch b posts the direct pieces and the first hops of
+    slice b together with the second hops of slice b - 1 out of the relays' buffers.  On RCCL the batches are consecutive groups
+    on one stream, so a link's second-hop traffic overlaps the first hops of the next slice and an exchange costs about what its
+    busiest link carries, not the sum of two rounds.  Both sides of every pair post their operations in the same canonical order
+    (batch, sorted pairs, paths in route order, segments in order), which is what matches messages between two ranks.
+    A message is a list of segments at its owner -- one for a packed send buffer, one per contiguous run when the runs travel
+    straight from psi -- and one contiguous range of the halo at its receiver."""
 
-    def __init__(self, op, routes, src, dst, per, group, finish=None):
+    def __init__(self, op, routes, src, dst, per, group, finish=None, nb=4):
         import torch
         import torch.distributed as dist
         me, nl = op.rank, op.n_local
-        send_at = {peer: off for (peer, off, cnt, _g) in op.send_slabs}
-        recv_at = {peer: off - nl for (peer, off, cnt, _g) in op.recv_slabs}
-        n_relay = sum(hi - lo for pr in routes for (k, lo, hi) in routes[pr] if k == me)
-        relay = torch.empty(max(n_relay, 1) * per, dtype=src.dtype, device=src.device)
-        r1, self._r2, slot = [], [], 0
-        for (o, r) in sorted(routes):
-            for (k, lo, hi) in routes[(o, r)]:
-                n = hi - lo
-                if k < 0:
-                    if me == o:
-                        r1.append(dist.P2POp(dist.isend, src[(send_at[r] + lo) * per:(send_at[r] + hi) * per], r, group))
-                    if me == r:
-                        r1.append(dist.P2POp(dist.irecv, dst[(recv_at[o] + lo) * per:(recv_at[o] + hi) * per], o, group))
-                    continue
+        runs = {}                                   # receiver -> [(offset in src, count)] of what I own and it needs, in order
+        for (peer, off, cnt, _g) in op.send_slabs:
+            runs.setdefault(peer, []).append((off, cnt))
+        recv_at, recv_runs = {}, {}                 # owner -> first halo element of its message; its segments (halo offset, count)
+        for (peer, off, cnt, _g) in op.recv_slabs:
+            recv_at.setdefault(peer, off - nl)
+            recv_runs.setdefault(peer, []).append((off - nl, cnt))
+
+        def cut(lst, lo, hi):
+            """[(offset, count)] of the elements [lo, hi) of a message laid out as the runs lst = [(offset, count), ...]"""
+            out, pos = [], 0
+            for (off, cnt) in lst:
+                a, b = max(lo, pos), min(hi, pos + cnt)
+                if a < b:
+                    out.append((off + a - pos, b - a))
+                pos += cnt
+            return out
+
+        n_of = {pr: sum(u for _k, u in lst) for pr, lst in routes.items()}
+        M = op._relay_M
+        relay_need = 0
+        plan = []                                   # (batch, o, r, via, lo, hi) in canonical order
+        for b in range(nb):
+            for (o, r) in sorted(routes):
+                n = M[(o, r)]
+                s_lo, s_hi = n * b // nb, n * (b + 1) // nb
+                u0 = 0
+                for (k, u) in routes[(o, r)]:
+                    lo = s_lo + (s_hi - s_lo) * u0 // n_of[(o, r)]
+                    hi = s_lo + (s_hi - s_lo) * (u0 + u) // n_of[(o, r)]
+                    u0 += u
+                    if hi > lo:
+                        plan.append((b, o, r, k, lo, hi))
+                        if k == me:
+                            relay_need += hi - lo
+        relay = torch.empty(max(relay_need, 1) * per, dtype=src.dtype, device=src.device)
+        self._batches = [[] for _ in range(nb + 1)]
+        slot = 0
+        for (b, o, r, k, lo, hi) in plan:
+            n = hi - lo
+            if k < 0:
                 if me == o:
-                    r1.append(dist.P2POp(dist.isend, src[(send_at[r] + lo) * per:(send_at[r] + hi) * per], k, group))
-                if me == k:
-                    buf = relay[slot * per:(slot + n) * per]
-                    slot += n
-                    r1.append(dist.P2POp(dist.irecv, buf, o, group))
-                    self._r2.append(dist.P2POp(dist.isend, buf, r, group))
-                if me == r:
-                    self._r2.append(dist.P2POp(dist.irecv, dst[(recv_at[o] + lo) * per:(recv_at[o] + hi) * per], k, group))
+                    for (off, cnt) in cut(runs[r], lo, hi):
+                        self._batches[b].append(dist.P2POp(dist.isend, src[off * per:(off + cnt) * per], r, group))
+                if me == r:                         # the same segments as the owner sends: its runs, cut at the same places
+                    for (off, cnt) in cut(recv_runs[o], lo, hi):
+                        self._batches[b].append(dist.P2POp(dist.irecv, dst[off * per:(off + cnt) * per], o, group))
+                continue
+            if me == o:
+                for (off, cnt) in cut(runs[r], lo, hi):
+                    self._batches[b].append(dist.P2POp(dist.isend, src[off * per:(off + cnt) * per], k, group))
+            if me == k:                             # the owner's segments arrive back to back in one slot; forwarded as one piece
+                buf = relay[slot * per:(slot + n) * per]
+                slot += n
+                pos = 0
+                for cnt in op._relay_runs_of(o, r, lo, hi):
+                    self._batches[b].append(dist.P2POp(dist.irecv, buf[pos * per:(pos + cnt) * per], o, group))
+                    pos += cnt
+                self._batches[b + 1].append(dist.P2POp(dist.isend, buf, r, group))
+            if me == r:
+                self._batches[b + 1].append(dist.P2POp(dist.irecv, dst[(recv_at[o] + lo) * per:(recv_at[o] + hi) * per], k, group))
         self._relay, self._finish, self._dist = relay, finish, dist
-        self._reqs = dist.batch_isend_irecv(r1) if r1 else []
+        self._staged = dist.get_backend(group) != "nccl"
+        self._reqs = []
+        self._next = 0
+        self._post()                                # NCCL: every batch is queued now (consecutive groups on one stream); gloo: batch 0
+
+    def _post(self):
+        while self._next < len(self._batches):
+            ops = self._batches[self._next]
+            self._next += 1
+            if ops:
+                self._reqs.extend(self._dist.batch_isend_irecv(ops))
+            if self._staged:
+                return                              # host-staged transports complete a batch before the next one is posted
 
     def wait(self):
-        for r in self._reqs:
-            r.wait()
-        for r in (self._dist.batch_isend_irecv(self._r2) if self._r2 else []):
-            r.wait()
+        while True:
+            for r in self._reqs:
+                r.wait()
+            self._reqs = []
+            if self._next >= len(self._batches):
+                break
+            self._post()
         if self._finish is not None:
             self._finish()
 
@@ -162,7 +231,7 @@ class TorchComm:
             routes = op.relay_plan(self.group)
             if routes is not None:
                 fin = (lambda: dst_dev.copy_(dst)) if staged else None
-                self._reqs = [_RelayExchange(op, routes, src, dst, per, self.group, fin)]
+                self._reqs = [_RelayExchange(op, routes, src, dst, per, self.group, fin, int(os.environ.get("SD_RELAY_BATCHES", "4")))]
                 return 0
             ops = []
             for (peer, off, cnt, _g) in op.recv_slabs:
@@ -260,26 +329,36 @@ class ShardedOperator:
 
     def relay_plan(self, group=None):
         """Routes of relay_routes for this operator's exchange, or None: built once, collectively, from every rank's receive
-        list (one message per (owner, receiver) pair in class mode)."""
+        list -- per (owner, receiver) pair the lengths of the segments the message consists of (one for a packed send buffer, one
+        per contiguous run when the runs travel straight from psi).  Cell ownership, at least three ranks."""
         import os
         if self._routes is None:
             self._routes = False
-            if os.environ.get("SD_RELAY", "0") not in ("", "0") and self.packed and self.world >= 3 \
+            if os.environ.get("SD_RELAY", "0") not in ("", "0") and self.mode == "class" and self.world >= 3 \
                     and self._exchange_fn is None:
                 import torch.distributed as dist
-                mine = [(int(peer), int(cnt)) for (peer, off, cnt, _g) in self.recv_slabs]
-                if len({pr for pr, _c in mine}) != len(mine):
-                    mine = None                      # several slabs per pair (not the case in class mode): no relays
+                mine = {}
+                for (peer, _off, cnt, _g) in self.recv_slabs:
+                    mine.setdefault(int(peer), []).append(int(cnt))
                 everyone = [None] * self.world
                 dist.all_gather_object(everyone, mine, group=group)
-                if any(lst is None for lst in everyone):
-                    return None
-                M = {(o, r): cnt for r, lst in enumerate(everyone) for (o, cnt) in lst}
-                routes = relay_routes(M, int(os.environ.get("SD_RELAY_CHUNKS", "8")), int(os.environ.get("SD_RELAY_MIN", "65536")),
-                                      force=os.environ.get("SD_RELAY") == "2")
-                if any(k >= 0 for lst in routes.values() for (k, _lo, _hi) in lst):
+                self._relay_runs = {(o, r): lst for r, d in enumerate(everyone) for o, lst in d.items()}
+                self._relay_M = {pr: sum(lst) for pr, lst in self._relay_runs.items()}
+                routes = relay_routes(self._relay_M, int(os.environ.get("SD_RELAY_CHUNKS", "8")),
+                                      int(os.environ.get("SD_RELAY_MIN", "65536")), force=os.environ.get("SD_RELAY") == "2")
+                if any(k >= 0 for lst in routes.values() for (k, _u) in lst):
                     self._routes = routes
         return self._routes or None
+
+    def _relay_runs_of(self, o, r, lo, hi):
+        """Lengths of the segments in which the elements [lo, hi) of message o -> r travel from their owner."""
+        out, pos = [], 0
+        for cnt in self._relay_runs[(o, r)]:
+            a, b = max(lo, pos), min(hi, pos + cnt)
+            if a < b:
+                out.append(b - a)
+            pos += cnt
+        return out
 
     def comm(self, device, group=None):
         """The communicator handed to the C recursion-level entry points (None for a single rank).
@@ -409,7 +488,7 @@ class ShardedOperator:
         if routes is not None:
             per = 2 if out.is_complex() else 1
             fin = (lambda: dst_dev.copy_(dst)) if staged else None
-            return halo, [_RelayExchange(self, routes, src.reshape(-1), dst.reshape(-1), per, group, fin)]
+            return halo, [_RelayExchange(self, routes, src.reshape(-1), dst.reshape(-1), per, group, fin, int(os.environ.get("SD_RELAY_BATCHES", "4")))]
         ops = []
         for (peer, off, cnt, _g) in self.recv_slabs:          # recv offsets are counted from the start of [owned | halo]
             ops.append(dist.P2POp(dist.irecv, dst[off - nl:off - nl + cnt], peer, group))

@@ -25,7 +25,8 @@ def _worker(rank, world, port, L, nup, mode, q, relay=False):
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                           SD_SUFFIX_BITS="6")
         if relay:                                            # two-hop routes for every message, however small
-            os.environ.update(SD_RELAY="2", SD_RELAY_MIN="0", SD_RELAY_CHUNKS="4", SD_SHARD_PACK="1")
+            os.environ.update(SD_RELAY="2", SD_RELAY_MIN="0", SD_RELAY_CHUNKS="4", SD_RELAY_BATCHES="3",
+                              SD_SHARD_PACK="1" if relay == "packed" else "0")
         if mode == "class-direct":                           # cell ownership, contiguous runs sent straight from the vector (large plans)
             os.environ.update(SD_SHARD_PACK="0")
             mode = "class"
@@ -67,7 +68,7 @@ def _worker(rank, world, port, L, nup, mode, q, relay=False):
         d = op.dot(buf, 2j * buf)                          # conjugate-linear in the first argument, summed over ranks
         ok = bool(ok and abs(d - 2j * np.vdot(psi, psi)) <= 1e-12 * abs(np.vdot(psi, psi)))
         routes = op.relay_plan()
-        n_relayed = 0 if routes is None else sum(hi - lo for lst in routes.values() for (k, lo, hi) in lst if k >= 0)
+        n_relayed = 0 if routes is None else sum(u for lst in routes.values() for (k, u) in lst if k >= 0)
         dist.barrier()
         dist.destroy_process_group()
         q.put((rank, ok, op.n_local, op.n_halo, nrm, float(np.linalg.norm(psi)), n_relayed))
@@ -93,15 +94,17 @@ def test_halo_exchange_gloo(world, L, nup, mode):
     assert sum(r[2] for r in res) > 0 and any(r[3] > 0 for r in res)
 
 
-@pytest.mark.parametrize("world,L,nup", [(3, 14, 6), (4, 16, 8)])
-def test_halo_exchange_with_two_hop_relays_gloo(world, L, nup):
-    """SD_RELAY=1: the pieces of every halo message travel either directly or owner -> relay -> receiver (dist.relay_routes,
-    the routing simulated in profiles/relay_sim.py); the halo must come out exactly as with direct messages."""
+@pytest.mark.parametrize("world,L,nup,form", [(3, 14, 6, "packed"), (4, 16, 8, "packed"), (3, 14, 6, "runs"), (4, 16, 8, "runs"),
+                                              (8, 20, 10, "runs")])
+def test_halo_exchange_with_two_hop_relays_gloo(world, L, nup, form):
+    """SD_RELAY=1: the pieces of every halo message travel either directly or owner -> relay -> receiver (dist.relay_routes),
+    pipelined in batches (the second hop of one slice beside the first hop of the next); the halo must come out exactly as with
+    direct messages, for a packed send buffer and for contiguous runs sent straight from the vector, with 3, 4 and 8 ranks."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, L, nup, "class", q, True)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, L, nup, "class", q, form)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=180) for _ in procs]
