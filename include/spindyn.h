@@ -376,6 +376,22 @@ int sd_comm_from_callbacks(const sd_comm_callbacks *cb, int rank, int nranks, sd
 int sd_comm_rccl_unique_id(void *id128);
 int sd_comm_rccl_create(sd_ctx *ctx, int rank, int nranks, const void *id128, sd_comm **out);
 void sd_comm_destroy(sd_comm *comm);
+/* Routed halo exchange (RCCL communicator).  By default an exchange is one grouped ncclSend / ncclRecv of the model's slab lists
+ * (sd_model_shard_slabs): every (owner, receiver) pair's bytes ride the one xGMI link that joins the pair, and the busiest pair
+ * carries two to three times the mean.  This installs an explicit list instead: operations in ascending `batch` order, one RCCL
+ * group per batch on the exchange stream, `buf` naming what `offset` (in elements) counts from -- 0 the vector handed to the
+ * exchange (sends only), 1 the halo buffer (receives only), 2 this rank's relay buffer of `relay_elems` elements (a piece
+ * received in batch b is forwarded in batch b + 1).  Every rank must install lists that pair up (the Python mirror builds them
+ * from one routing plan: dist.relay_routes / dist.relay_ops).  n_ops == 0 restores the default. */
+typedef struct sd_xop {
+  int batch;        /* ascending through the list */
+  int peer;
+  int kind;         /* 0 send, 1 receive */
+  int buf;          /* 0 vector, 1 halo, 2 relay buffer */
+  int64_t offset;   /* elements from the start of that buffer */
+  int64_t count;    /* elements */
+} sd_xop;
+int sd_comm_set_exchange_ops(sd_comm *comm, const sd_xop *ops, int64_t n_ops, int64_t relay_elems);
 /* Diagnostic (RCCL communicator): ncclAllReduce of two device doubles and a grouped ncclSend/ncclRecv round the ring of ranks
  * (rank -> rank+1; to itself with nranks == 1), bytes checked.  Collective: with more than one rank all of them must call it. */
 int sd_comm_selftest(sd_ctx *ctx, sd_comm *comm);

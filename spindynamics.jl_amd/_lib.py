@@ -69,6 +69,10 @@ EXCHANGE_WAIT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int)
 
 
+class sd_xop(C.Structure):
+    _fields_ = [("batch", C.c_int), ("peer", C.c_int), ("kind", C.c_int), ("buf", C.c_int), ("offset", C.c_int64), ("count", C.c_int64)]
+
+
 class sd_comm_callbacks(C.Structure):
     _fields_ = [("user", C.c_void_p), ("exchange_start", EXCHANGE_START_FN), ("exchange_wait", EXCHANGE_WAIT_FN),
                 ("allreduce_sum", ALLREDUCE_FN)]
@@ -148,6 +152,7 @@ PROTOTYPES = {
     "sd_comm_rccl_unique_id": (_i, [_vp]),
     "sd_comm_rccl_create": (_i, [_vp, _i, _i, _vp, C.POINTER(_vp)]),
     "sd_comm_destroy": (None, [_vp]),
+    "sd_comm_set_exchange_ops": (_i, [_vp, C.POINTER(sd_xop), _i64, _i64]),
     "sd_comm_selftest": (_i, [_vp, _vp]),
     "sd_apply_sharded": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i64, _i]),
     "sd_lanczos_extremal_sharded": (_i, [_vp, _vp, _vp, _i, _d, _vp, _u64, _i, _dp, _dp]),

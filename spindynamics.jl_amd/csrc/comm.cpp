@@ -12,6 +12,7 @@
 //     (gloo in the rehearsals on one GPU); scalars take one host round trip per reduction.
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -82,6 +83,12 @@ struct sd_comm {
   int device = 0;
   hipStream_t xstream = nullptr;            // the slab exchange runs here, beside the interior tiles on the compute stream
   hipEvent_t ev_ready = nullptr, ev_done = nullptr;
+  // routed exchange (sd_comm_set_exchange_ops): the halo exchange as an explicit list of sends / receives in batches, with a
+  // relay buffer of this rank for pieces that travel owner -> relay -> receiver; empty: the model's slab lists, all at once
+  std::vector<sd_xop> xops;
+  int64_t relay_elems = 0;
+  void *relay = nullptr;
+  size_t relay_bytes = 0;
 };
 
 int sd_comm_nranks(const sd_comm *c) { return c ? c->nranks : 1; }
@@ -100,6 +107,37 @@ int sd_comm_exchange_start(sd_ctx *ctx, sd_comm *c, const sd_model *m, int dtype
   SD_HIP(ctx, hipStreamWaitEvent(c->xstream, c->ev_ready, 0));
   // an error inside the group must not leave the thread's group open (later RCCL calls would be deferred for ever): note the
   // first failure, close the group regardless, then report
+  if (!c->xops.empty()) {
+    // A routed exchange: one RCCL group per batch, in order, on the exchange stream.  A relay's receive of a piece (batch b) and its
+    // forwarding (batch b + 1) are ordered by that stream; consecutive groups overlap on the links, so the second hop of one
+    // slice travels while the first hop of the next is under way.
+    const size_t need = (size_t)std::max<int64_t>(c->relay_elems, 1) * 16;
+    if (c->relay_bytes < need) {
+      if (c->relay) (void)hipFree(c->relay);
+      c->relay = nullptr; c->relay_bytes = 0;
+      SD_HIP(ctx, hipMalloc(&c->relay, need));
+      c->relay_bytes = need;
+    }
+    int nb = 0;
+    for (const sd_xop &o : c->xops) nb = std::max(nb, o.batch + 1);
+    size_t at = 0;
+    for (int b = 0; b < nb; ++b) {
+      SD_NCCL(ctx, c, c->api->GroupStart());
+      int bad = 0;
+      for (; at < c->xops.size() && c->xops[at].batch == b && !bad; ++at) {
+        const sd_xop &o = c->xops[at];
+        double *base = o.buf == 0 ? (double *)const_cast<void *>(src) : o.buf == 1 ? (double *)halo : (double *)c->relay;
+        double *p = base + (size_t)o.offset * per;
+        bad = o.kind == 0 ? c->api->Send(p, (size_t)o.count * per, NCCL_DOUBLE, o.peer, c->nccl, c->xstream)
+                          : c->api->Recv(p, (size_t)o.count * per, NCCL_DOUBLE, o.peer, c->nccl, c->xstream);
+      }
+      const int end = c->api->GroupEnd();
+      if (bad) return sd_set_err(ctx, SD_ECOMM, std::string("ncclSend/ncclRecv of the routed halo exchange: ") + c->api->GetErrorString(bad));
+      if (end) return sd_set_err(ctx, SD_ECOMM, std::string("ncclGroupEnd: ") + c->api->GetErrorString(end));
+    }
+    SD_HIP(ctx, hipEventRecord(c->ev_done, c->xstream));
+    return SD_OK;
+  }
   SD_NCCL(ctx, c, c->api->GroupStart());
   int bad = 0;
   for (const sd_slab &s : m->recv_slabs) {          // recv offsets are counted from the start of [owned | halo]
@@ -156,6 +194,23 @@ int sd_comm_from_callbacks(const sd_comm_callbacks *cb, int rank, int nranks, sd
   if (!c) return SD_ENOMEM;
   c->kind = 0; c->cb = *cb; c->rank = rank; c->nranks = nranks;
   *out = c;
+  return SD_OK;
+}
+
+int sd_comm_set_exchange_ops(sd_comm *c, const sd_xop *ops, int64_t n_ops, int64_t relay_elems) {
+  if (!c || n_ops < 0 || relay_elems < 0 || (n_ops > 0 && !ops)) return SD_EARG;
+  if (c->kind != 1) return SD_EARG;                 // a callback communicator routes its own exchange
+  int last = 0;
+  for (int64_t i = 0; i < n_ops; ++i) {
+    const sd_xop &o = ops[i];
+    if (o.batch < last || o.peer < 0 || o.peer >= c->nranks || o.peer == c->rank || (o.kind != 0 && o.kind != 1) || o.buf < 0 ||
+        o.buf > 2 || o.offset < 0 || o.count <= 0 || (o.kind == 0 && o.buf == 1) || (o.kind == 1 && o.buf == 0) ||
+        (o.buf == 2 && o.offset + o.count > relay_elems))
+      return SD_EARG;                               // batches ascending; sends read the vector or the relay buffer, receives fill the halo or the relay buffer
+    last = o.batch;
+  }
+  try { c->xops.assign(ops, ops + n_ops); } catch (const std::bad_alloc &) { return SD_ENOMEM; }
+  c->relay_elems = relay_elems;
   return SD_OK;
 }
 
@@ -249,6 +304,7 @@ void sd_comm_destroy(sd_comm *c) {
     if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
     if (c->ev_done) (void)hipEventDestroy(c->ev_done);
     if (c->xstream) (void)hipStreamDestroy(c->xstream);
+    if (c->relay) (void)hipFree(c->relay);
   }
   delete c;
 }

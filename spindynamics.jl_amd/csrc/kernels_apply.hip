@@ -63,6 +63,9 @@ namespace {
 #ifndef SD_SKIP_DEAD_ROWS
 #define SD_SKIP_DEAD_ROWS 1
 #endif
+#ifndef SD_SKIP_DEAD_C128
+#define SD_SKIP_DEAD_C128 0     // (round 4, wave-contiguous rows: A/B in profiles/ablation_r04.md)
+#endif
 #ifndef SD_LB_C128
 #define SD_LB_C128 4
 #endif
@@ -187,7 +190,7 @@ __global__ __launch_bounds__(BLOCK, (NC == 2 ? SD_LB_C128 : SD_LB_F64)) void k_a
   // stay zero.  The range check would return zeros for them anyway, but every such load still costs the address unit its
   // cycles (TA busy 70 % of the launch, ablation_r03.md section 5).
   // Float64 only: measured -2...3 % there, but +5 % for ComplexF64 (round 3).
-  constexpr bool SKIP_DEAD = SD_SKIP_DEAD_ROWS && NC == 1;
+  constexpr bool SKIP_DEAD = SD_SKIP_DEAD_ROWS && (NC == 1 || SD_SKIP_DEAD_C128);
   uint32_t live = 0;
   if (SKIP_DEAD) {
 #pragma unroll

@@ -95,81 +95,93 @@ def relay_link_loads(M, routes):
     return load
 
 
+def relay_ops(op, routes, nb=4):
+    """The operations of ONE rank for a halo exchange over `routes`, pipelined in nb + 1 batches: a list of
+    (batch, peer, kind, buf, offset, count) with kind 0 = send / 1 = receive, buf 0 = the vector (or packed send buffer) / 1 = the
+    halo buffer / 2 = this rank's relay buffer, offsets and counts in elements -- and the relay buffer's size.  Every message is
+    cut into nb slices, each slice into the sub-ranges its paths carry (in proportion to their routing units); batch b holds the
+    direct pieces and the first hops of slice b and the second hops of slice b - 1.  All ranks walk the same canonical order
+    (batch, sorted pairs, paths in route order, segments in order), which is what pairs a send with its receive.  A message is
+    a list of segments at its owner -- one for a packed send buffer, one per contiguous run when runs travel straight from psi --
+    and one contiguous range of the halo at its receiver; a relay receives the owner's segments back to back and forwards them as
+    one piece.  Shared by the torch.distributed transport (_RelayExchange) and the library's RCCL communicator
+    (sd_comm_set_exchange_ops)."""
+    me, nl = op.rank, op.n_local
+    runs = {}                                   # receiver -> [(offset in the vector, count)] of what I own and it needs, in order
+    for (peer, off, cnt, _g) in op.send_slabs:
+        runs.setdefault(peer, []).append((off, cnt))
+    recv_at, recv_runs = {}, {}                 # owner -> first halo element of its message; its segments (halo offset, count)
+    for (peer, off, cnt, _g) in op.recv_slabs:
+        recv_at.setdefault(peer, off - nl)
+        recv_runs.setdefault(peer, []).append((off - nl, cnt))
+
+    def cut(lst, lo, hi):
+        """[(offset, count)] of the elements [lo, hi) of a message laid out as the runs lst = [(offset, count), ...]"""
+        out, pos = [], 0
+        for (off, cnt) in lst:
+            a, b = max(lo, pos), min(hi, pos + cnt)
+            if a < b:
+                out.append((off + a - pos, b - a))
+            pos += cnt
+        return out
+
+    M = op._relay_M
+    ops, slot = [], 0
+    second = []                                 # second hops, posted one batch later
+    for b in range(nb):
+        for (o, r) in sorted(routes):
+            n = M[(o, r)]
+            units = sum(u for _k, u in routes[(o, r)])
+            s_lo, s_hi = n * b // nb, n * (b + 1) // nb
+            u0 = 0
+            for (k, u) in routes[(o, r)]:
+                lo = s_lo + (s_hi - s_lo) * u0 // units
+                hi = s_lo + (s_hi - s_lo) * (u0 + u) // units
+                u0 += u
+                if hi <= lo:
+                    continue
+                if k < 0:
+                    if me == o:
+                        ops += [(b, r, 0, 0, off, cnt) for (off, cnt) in cut(runs[r], lo, hi)]
+                    if me == r:                 # the same segments as the owner sends: its runs, cut at the same places
+                        ops += [(b, o, 1, 1, off, cnt) for (off, cnt) in cut(recv_runs[o], lo, hi)]
+                    continue
+                if me == o:
+                    ops += [(b, k, 0, 0, off, cnt) for (off, cnt) in cut(runs[r], lo, hi)]
+                if me == k:
+                    pos = slot
+                    for cnt in op._relay_runs_of(o, r, lo, hi):
+                        ops.append((b, o, 1, 2, pos, cnt))
+                        pos += cnt
+                    second.append((b + 1, r, 0, 2, slot, hi - lo))
+                    slot = pos
+                if me == r:
+                    second.append((b + 1, k, 1, 1, recv_at[o] + lo, hi - lo))
+    # merge: within a batch, first hops / direct pieces of slice b come before the second hops of slice b - 1 on EVERY rank
+    allops = sorted(range(len(ops)), key=lambda i: ops[i][0])
+    out = []
+    for b in range(nb + 1):
+        out += [ops[i] for i in allops if ops[i][0] == b]
+        out += [x for x in second if x[0] == b]
+    return out, slot
+
+
 class _RelayExchange:
-    """One halo exchange over the routes of relay_routes, pipelined: every message is cut into `nb` slices, each slice into the
-    sub-ranges its paths carry (in proportion to their routing units); batch b posts the direct pieces and the first hops of
-    slice b together with the second hops of slice b - 1 out of the relays' buffers.  On RCCL the batches are consecutive groups
-    on one stream, so a link's second-hop traffic overlaps the first hops of the next slice and an exchange costs about what its
-    busiest link carries, not the sum of two rounds.  Both sides of every pair post their operations in the same canonical order
-    (batch, sorted pairs, paths in route order, segments in order), which is what matches messages between two ranks.
-    A message is a list of segments at its owner -- one for a packed send buffer, one per contiguous run when the runs travel
-    straight from psi -- and one contiguous range of the halo at its receiver."""
+    """One halo exchange over the routes of relay_routes on torch.distributed: the batches of relay_ops as batch_isend_irecv
+    calls.  On RCCL the batches are consecutive groups on one stream, so a link's second-hop traffic overlaps the first hops of
+    the next slice and an exchange costs about what its busiest link carries, not the sum of two rounds; host-staged transports
+    (gloo) complete a batch before the next one is posted."""
 
     def __init__(self, op, routes, src, dst, per, group, finish=None, nb=4):
         import torch
         import torch.distributed as dist
-        me, nl = op.rank, op.n_local
-        runs = {}                                   # receiver -> [(offset in src, count)] of what I own and it needs, in order
-        for (peer, off, cnt, _g) in op.send_slabs:
-            runs.setdefault(peer, []).append((off, cnt))
-        recv_at, recv_runs = {}, {}                 # owner -> first halo element of its message; its segments (halo offset, count)
-        for (peer, off, cnt, _g) in op.recv_slabs:
-            recv_at.setdefault(peer, off - nl)
-            recv_runs.setdefault(peer, []).append((off - nl, cnt))
-
-        def cut(lst, lo, hi):
-            """[(offset, count)] of the elements [lo, hi) of a message laid out as the runs lst = [(offset, count), ...]"""
-            out, pos = [], 0
-            for (off, cnt) in lst:
-                a, b = max(lo, pos), min(hi, pos + cnt)
-                if a < b:
-                    out.append((off + a - pos, b - a))
-                pos += cnt
-            return out
-
-        n_of = {pr: sum(u for _k, u in lst) for pr, lst in routes.items()}
-        M = op._relay_M
-        relay_need = 0
-        plan = []                                   # (batch, o, r, via, lo, hi) in canonical order
-        for b in range(nb):
-            for (o, r) in sorted(routes):
-                n = M[(o, r)]
-                s_lo, s_hi = n * b // nb, n * (b + 1) // nb
-                u0 = 0
-                for (k, u) in routes[(o, r)]:
-                    lo = s_lo + (s_hi - s_lo) * u0 // n_of[(o, r)]
-                    hi = s_lo + (s_hi - s_lo) * (u0 + u) // n_of[(o, r)]
-                    u0 += u
-                    if hi > lo:
-                        plan.append((b, o, r, k, lo, hi))
-                        if k == me:
-                            relay_need += hi - lo
-        relay = torch.empty(max(relay_need, 1) * per, dtype=src.dtype, device=src.device)
+        ops, n_relay = relay_ops(op, routes, nb)
+        relay = torch.empty(max(n_relay, 1) * per, dtype=src.dtype, device=src.device)
+        bufs = (src, dst, relay)
         self._batches = [[] for _ in range(nb + 1)]
-        slot = 0
-        for (b, o, r, k, lo, hi) in plan:
-            n = hi - lo
-            if k < 0:
-                if me == o:
-                    for (off, cnt) in cut(runs[r], lo, hi):
-                        self._batches[b].append(dist.P2POp(dist.isend, src[off * per:(off + cnt) * per], r, group))
-                if me == r:                         # the same segments as the owner sends: its runs, cut at the same places
-                    for (off, cnt) in cut(recv_runs[o], lo, hi):
-                        self._batches[b].append(dist.P2POp(dist.irecv, dst[off * per:(off + cnt) * per], o, group))
-                continue
-            if me == o:
-                for (off, cnt) in cut(runs[r], lo, hi):
-                    self._batches[b].append(dist.P2POp(dist.isend, src[off * per:(off + cnt) * per], k, group))
-            if me == k:                             # the owner's segments arrive back to back in one slot; forwarded as one piece
-                buf = relay[slot * per:(slot + n) * per]
-                slot += n
-                pos = 0
-                for cnt in op._relay_runs_of(o, r, lo, hi):
-                    self._batches[b].append(dist.P2POp(dist.irecv, buf[pos * per:(pos + cnt) * per], o, group))
-                    pos += cnt
-                self._batches[b + 1].append(dist.P2POp(dist.isend, buf, r, group))
-            if me == r:
-                self._batches[b + 1].append(dist.P2POp(dist.irecv, dst[(recv_at[o] + lo) * per:(recv_at[o] + hi) * per], k, group))
+        for (b, peer, kind, buf, off, cnt) in ops:
+            t = bufs[buf][off * per:(off + cnt) * per]
+            self._batches[b].append(dist.P2POp(dist.isend if kind == 0 else dist.irecv, t, peer, group))
         self._relay, self._finish, self._dist = relay, finish, dist
         self._staged = dist.get_backend(group) != "nccl"
         self._reqs = []
@@ -297,6 +309,21 @@ class RcclComm:
         m = op.model
         check(lib().sd_comm_rccl_create(m.ctx.h, op.rank, op.world, idbuf, C.byref(self.h)), m.ctx.h)
         self._err = None
+        self.routed = False
+
+    def set_routes(self, op, routes, nb=4):
+        """Install the pipelined two-hop exchange of `routes` (dist.relay_routes) in the library's communicator
+        (sd_comm_set_exchange_ops); routes None: back to one grouped send / receive of the slab lists."""
+        if routes is None:
+            check(lib().sd_comm_set_exchange_ops(self.h, None, 0, 0))
+            self.routed = False
+            return
+        ops, n_relay = relay_ops(op, routes, nb)
+        arr = (_lib.sd_xop * max(len(ops), 1))()
+        for i, (b, peer, kind, buf, off, cnt) in enumerate(ops):
+            arr[i] = _lib.sd_xop(int(b), int(peer), int(kind), int(buf), int(off), int(cnt))
+        check(lib().sd_comm_set_exchange_ops(self.h, arr, len(ops), int(n_relay)))
+        self.routed = True
 
     def close(self):
         if self.h:
@@ -395,6 +422,9 @@ class ShardedOperator:
                 dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
                 if float(t.item()) == 1.0:
                     self._comm, self.comm_kind = cm, "rccl"
+                    routes = self.relay_plan(group)          # SD_RELAY: the same routing the torch.distributed transport uses
+                    if routes is not None:
+                        cm.set_routes(self, routes, int(os.environ.get("SD_RELAY_BATCHES", "4")))
                 else:
                     if cm is not None:
                         cm.close()
