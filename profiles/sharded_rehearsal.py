@@ -86,7 +86,8 @@ for mode in ("class", "range"):
     routes = op.relay_plan()
     if routes is not None:          # SD_RELAY=1: which part of the exchange took two hops
         sys.stdout.write("rank %d mode %s relayed elements per exchange: %d of %d\n" % (
-            rank, mode, sum(hi - lo for lst in routes.values() for (k, lo, hi) in lst if k >= 0), sum(hi for lst in routes.values() for (k, lo, hi) in lst[-1:])))
+            rank, mode, sum(op._relay_M[pr] * u // sum(x for _k, x in lst) for pr, lst in routes.items() for (k, u) in lst if k >= 0),
+            sum(op._relay_M.values())))
     sys.stdout.flush()
 dist.barrier()
 dist.destroy_process_group()
