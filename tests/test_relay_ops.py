@@ -98,7 +98,7 @@ def test_routed_exchange_op_lists_deliver_the_direct_halo(pkg, L, nup, P, pack, 
         assert np.array_equal(halo[r], want[r])
 
 
-def test_relay_routes_balance_the_links():
+def test_relay_routes_balance_the_links(pkg):
     """A 4-rank ring-like matrix with one heavy pair: the heavy message is spread over idle links, the busiest link drops."""
     from spindynamics_jl_amd import dist as D
     M = {(0, 1): 8000, (1, 0): 8000, (2, 3): 1000, (3, 2): 1000, (1, 2): 1000, (2, 1): 1000}
