@@ -142,6 +142,175 @@ __global__ __launch_bounds__(64 * SD_BGS_B) void k_bgs_reduce(const double *__re
   if (lane == 0 && c < nc) dst[c] = a;
 }
 
+// ---- lanczos_groundstate without reduction launches and with the orthogonality check riding along (round 4) ----
+// The step of src/Lanczos.jl:111-156 as a chain of passes that hand their per-block partial sums straight to the next pass:
+// every block of the consumer sums the producer's list itself (column c by one wave, lane-strided then shuffled: one fixed
+// order on every block), so a pass is ONE launch and nothing but the check results crosses to the host.
+//   k_gs_pass: the blocked Gram-Schmidt link of k_proj_dots (same per-element arithmetic) with
+//     coef[c] = sum of the previous pass's partials, and -- CHK -- the dots of the same V2 columns with a second vector y: the
+//     orthogonality check of the PREVIOUS step (src/Lanczos.jl:142-153 wants dot(V[:,k], w/beta) for every k <= j; y = V[:,j+1]
+//     is that very vector), which so costs one more read of y per pass instead of a sweep over all columns of its own.
+__device__ __forceinline__ void gs_sum_cols(const double *__restrict__ part, int nb, int nc, double *out /* LDS, SD_BGS_B */) {
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int c = wv; c < SD_BGS_B; c += BS / 64) {
+    double a = 0.0;
+    if (c < nc) for (int b = lane; b < nb; b += 64) a += part[(size_t)b * SD_BGS_B + c];
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, 64);
+    if (lane == 0) out[c] = a;
+  }
+  __syncthreads();
+}
+template <bool CHK>
+__global__ __launch_bounds__(BS) void k_gs_pass(double *__restrict__ w, const double *__restrict__ V1, int64_t ld, int nc1,
+                                                const double *__restrict__ part_in, int nb_in, const double *__restrict__ V2, int nc2,
+                                                const double *__restrict__ y, int64_t N, double *__restrict__ part_out,
+                                                double *__restrict__ chk_out) {
+  __shared__ double red[BS / 64][2 * SD_BGS_B];
+  __shared__ double cfs[SD_BGS_B];
+  if (nc1 > 0) gs_sum_cols(part_in, nb_in, nc1, cfs);
+  double cf[SD_BGS_B], acc[SD_BGS_B], ac2[SD_BGS_B];
+#pragma unroll
+  for (int c = 0; c < SD_BGS_B; ++c) { cf[c] = c < nc1 ? cfs[c] : 0.0; acc[c] = 0.0; ac2[c] = 0.0; }
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const bool vec = (ld % 2 == 0) && !(((uintptr_t)w | (uintptr_t)V1 | (uintptr_t)V2 | (uintptr_t)(CHK ? y : w)) & 15);
+  const int64_t n2 = vec ? N / 2 : 0;
+  double2 *w2 = (double2 *)w;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
+    double2 x = w2[i];
+#pragma unroll
+    for (int c = 0; c < SD_BGS_B; ++c)
+      if (c < nc1) { const double2 v = ((const double2 *)(V1 + (int64_t)c * ld))[i]; x.x = x.x - cf[c] * v.x; x.y = x.y - cf[c] * v.y; }
+    if (nc1 > 0) w2[i] = x;
+    double2 yy = make_double2(0.0, 0.0);
+    if (CHK) yy = ((const double2 *)y)[i];
+#pragma unroll
+    for (int c = 0; c < SD_BGS_B; ++c)
+      if (c < nc2) {
+        const double2 v = ((const double2 *)(V2 + (int64_t)c * ld))[i];
+        acc[c] += v.x * x.x + v.y * x.y;
+        if (CHK) ac2[c] += v.x * yy.x + v.y * yy.y;
+      }
+  }
+  for (int64_t i = 2 * n2 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += stride) {
+    double x = w[i];
+#pragma unroll
+    for (int c = 0; c < SD_BGS_B; ++c)
+      if (c < nc1) x = x - cf[c] * V1[(int64_t)c * ld + i];
+    if (nc1 > 0) w[i] = x;
+    const double yi = CHK ? y[i] : 0.0;
+#pragma unroll
+    for (int c = 0; c < SD_BGS_B; ++c)
+      if (c < nc2) { const double v = V2[(int64_t)c * ld + i]; acc[c] += v * x; if (CHK) ac2[c] += v * yi; }
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int c = 0; c < SD_BGS_B; ++c) {
+    double a = acc[c], b = ac2[c];
+    for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off, 64); if (CHK) b += __shfl_down(b, off, 64); }
+    if (lane == 0) { red[wv][c] = a; red[wv][SD_BGS_B + c] = b; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 2 * SD_BGS_B) {
+    double a = 0.0;
+    for (int k = 0; k < BS / 64; ++k) a += red[k][threadIdx.x];
+    if (threadIdx.x < SD_BGS_B) part_out[(size_t)blockIdx.x * SD_BGS_B + threadIdx.x] = a;
+    else if (CHK) chk_out[(size_t)blockIdx.x * SD_BGS_B + (threadIdx.x - SD_BGS_B)] = a;
+  }
+}
+//   k_gs_update: alpha_j = sum of the last pass's partials (column 0), beta_{j-1} = sqrt(sum of the previous step's |w|^2 partials);
+//     w = (w - alpha v_j) - beta_{j-1} v_{j-1}  (src/Lanczos.jl:127-129).  The full re-orthogonalisation has already removed the
+//     v_{j-1} component, so this puts -beta_{j-1} v_{j-1} back in, and the reference's check loop (:142-153) finds it at k = j-1 on
+//     EVERY step and repairs it.  That repair is part of the normal flow: the pass also forms the partials of
+//     d = dot(v_{j-1}, w) (column 1) for k_gs_correct.  Column 0 of the output: |w|^2 partials (used when there is no v_{j-1}).
+__global__ __launch_bounds__(BS) void k_gs_update(double *__restrict__ w, const double *__restrict__ vj, const double *__restrict__ vjm1,
+                                                  int64_t N, const double *__restrict__ alpha_part, int nb_a,
+                                                  const double *__restrict__ n2_prev, int nb_n, double *__restrict__ store_alpha,
+                                                  double *__restrict__ store_beta, double *__restrict__ out_part) {
+  __shared__ double red[32];
+  __shared__ double sc[SD_BGS_B], sn[SD_BGS_B];
+  gs_sum_cols(alpha_part, nb_a, 1, sc);
+  if (vjm1) gs_sum_cols(n2_prev, nb_n, 1, sn);
+  const double a = sc[0], b = vjm1 ? sqrt(sn[0]) : 0.0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { *store_alpha = a; if (vjm1) *store_beta = b; }
+  double s = 0.0, d = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const bool vec = !(((uintptr_t)w | (uintptr_t)vj | (uintptr_t)(vjm1 ? vjm1 : vj)) & 15);
+  const int64_t n2 = vec ? N / 2 : 0;
+  double2 *w2 = (double2 *)w;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
+    double2 x = w2[i];
+    const double2 v = ((const double2 *)vj)[i];
+    x.x = x.x - a * v.x; x.y = x.y - a * v.y;
+    if (vjm1) {
+      const double2 u = ((const double2 *)vjm1)[i];
+      x.x = x.x - b * u.x; x.y = x.y - b * u.y;
+      d += u.x * x.x + u.y * x.y;
+    }
+    w2[i] = x;
+    s += x.x * x.x + x.y * x.y;
+  }
+  for (int64_t i = 2 * n2 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += stride) {
+    double x = w[i] - a * vj[i];
+    if (vjm1) { x = x - b * vjm1[i]; d += vjm1[i] * x; }
+    w[i] = x;
+    s += x * x;
+  }
+  __syncthreads();
+  block_reduce2(s, d, red);
+  if (threadIdx.x == 0) { out_part[(size_t)blockIdx.x * SD_BGS_B] = s; out_part[(size_t)blockIdx.x * SD_BGS_B + 1] = d; }
+}
+//   k_gs_correct: d = sum of column 1 of the update's partials; w -= d v_{j-1}  (the reference's correction at k = j-1, :147);
+//     |w|^2 partials out (column 0): beta_j = norm(w) after the correction (:148).
+__global__ __launch_bounds__(BS) void k_gs_correct(double *__restrict__ w, const double *__restrict__ vjm1, int64_t N,
+                                                   const double *__restrict__ upd_part, int nb_u, double *__restrict__ n2_out) {
+  __shared__ double red[32];
+  __shared__ double sc[SD_BGS_B];
+  gs_sum_cols(upd_part + 1, nb_u, 1, sc);                   // column 1
+  const double d = sc[0];
+  double s = 0.0, s1 = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const bool vec = !(((uintptr_t)w | (uintptr_t)vjm1) & 15);
+  const int64_t n2 = vec ? N / 2 : 0;
+  double2 *w2 = (double2 *)w;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
+    double2 x = w2[i];
+    const double2 u = ((const double2 *)vjm1)[i];
+    x.x = x.x - d * u.x; x.y = x.y - d * u.y;
+    w2[i] = x;
+    s += x.x * x.x + x.y * x.y;
+  }
+  for (int64_t i = 2 * n2 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += stride) {
+    const double x = w[i] - d * vjm1[i];
+    w[i] = x;
+    s += x * x;
+  }
+  __syncthreads();
+  block_reduce2(s, s1, red);
+  if (threadIdx.x == 0) n2_out[(size_t)blockIdx.x * SD_BGS_B] = s;
+}
+//   k_gs_scale: v_{j+1} = w / beta_j with beta_j = sqrt(sum of |w|^2 partials)  (src/Lanczos.jl:155); one thread files beta_j.
+__global__ __launch_bounds__(BS) void k_gs_scale(double *__restrict__ vnext, const double *__restrict__ w, int64_t N,
+                                                 const double *__restrict__ n2_part, int nb_n, double *__restrict__ store_beta) {
+  __shared__ double sn[SD_BGS_B];
+  gs_sum_cols(n2_part, nb_n, 1, sn);
+  const double b = sqrt(sn[0]);
+  if (blockIdx.x == 0 && threadIdx.x == 0) *store_beta = b;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const bool vec = !(((uintptr_t)w | (uintptr_t)vnext) & 15);
+  const int64_t n2 = vec ? N / 2 : 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
+    const double2 x = ((const double2 *)w)[i];
+    ((double2 *)vnext)[i] = make_double2(x.x / b, x.y / b);
+  }
+  for (int64_t i = 2 * n2 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += stride) vnext[i] = w[i] / b;
+}
+//   k_gs_chk_reduce: the check dots of all passes of a chain (pass p, column c -> chk[8 p + c]); block p reduces pass p.
+__global__ __launch_bounds__(BS) void k_gs_chk_reduce(const double *__restrict__ chk_part, int nb, double *__restrict__ chk) {
+  __shared__ double out[SD_BGS_B];
+  gs_sum_cols(chk_part + (size_t)blockIdx.x * nb * SD_BGS_B, nb, SD_BGS_B, out);
+  if (threadIdx.x < SD_BGS_B) chk[(size_t)blockIdx.x * SD_BGS_B + threadIdx.x] = out[threadIdx.x];
+}
+
 // One link of the modified Gram-Schmidt chain of lanczos_groundstate (src/Lanczos.jl:116-124) without a host round trip:
 //   if (v_sub) w -= (*s_dev) * v_sub;      then   partial sums of  v_dot . w   (reduced into a device scalar by k_reduce_to)
 // The next link reads that scalar on the device.  Same element order per thread as k_dot<1> / k_ew2 when the vectors are
@@ -560,6 +729,58 @@ int sd_k_bgs_chain(sd_ctx *ctx, double *w, const double *V, int64_t ld, int ncol
     hipLaunchKernelGGL(k_bgs_reduce, dim3(1), dim3(64 * SD_BGS_B), 0, ctx->stream, ctx->d_partials, nb, nc2, dst);
     cur ^= 1;
   }
+  SD_HIP(ctx, hipGetLastError());
+  return SD_OK;
+}
+
+// blocks of the fused groundstate passes (their partial lists are summed by every block of the consumer: at most 1024)
+int sd_k_gs_blocks(int64_t N) { return (int)std::min<int64_t>(1024, std::max<int64_t>(1, (N / 2 + BS - 1) / BS)); }
+// Blocked Gram-Schmidt of w against V[:,0..ncols-2] (blocks of 8, as sd_k_bgs_chain) ending with the partials of
+// alpha = V[:,ncols-1] . w in alpha_part[block][0]; one launch per pass.  y != null: the dots of y with V[:,0..ncols-2] ride along
+// and land in chk_dev[0..ncols-2] (device).  scratch: (2 + npass) * nb * 8 doubles, npass = (ncols-2)/8 + 2.
+int sd_k_gs_chain(sd_ctx *ctx, double *w, const double *V, int64_t ld, int ncols, int64_t N, const double *y, double *scratch,
+                  double *alpha_part, double *chk_dev) {
+  const int nb = sd_k_gs_blocks(N);
+  const int nproj = ncols - 1;
+  const double *vlast = V + (int64_t)(ncols - 1) * ld;
+  double *part[2] = {scratch, scratch + (size_t)nb * SD_BGS_B};
+  double *chk_part = scratch + 2 * (size_t)nb * SD_BGS_B;
+  int cur = 0, pass = 0;
+  auto launch = [&](const double *V1, int nc1, const double *pin, const double *V2, int nc2, double *pout, bool chk) {
+    double *co = chk_part + (size_t)pass * nb * SD_BGS_B;
+    if (chk) hipLaunchKernelGGL(k_gs_pass<true>, dim3(nb), dim3(BS), 0, ctx->stream, w, V1, ld, nc1, pin, nb, V2, nc2, y, N, pout, co);
+    else hipLaunchKernelGGL(k_gs_pass<false>, dim3(nb), dim3(BS), 0, ctx->stream, w, V1, ld, nc1, pin, nb, V2, nc2, y, N, pout, co);
+  };
+  // first pass: dots only (nothing to subtract yet)
+  if (nproj > 0) { launch(V, 0, part[cur], V, std::min(SD_BGS_B, nproj), part[cur], y != nullptr); ++pass; }
+  else launch(V, 0, part[cur], vlast, 1, alpha_part, false);
+  for (int c0 = 0; c0 < nproj; c0 += SD_BGS_B) {
+    const int nc1 = std::min(SD_BGS_B, nproj - c0), c1 = c0 + nc1;
+    const bool more = c1 < nproj;
+    const int nc2 = more ? std::min(SD_BGS_B, nproj - c1) : 1;
+    launch(V + (int64_t)c0 * ld, nc1, part[cur], more ? V + (int64_t)c1 * ld : vlast, nc2, more ? part[cur ^ 1] : alpha_part,
+           more && y != nullptr);
+    if (more) ++pass;
+    cur ^= 1;
+  }
+  if (y && pass > 0) hipLaunchKernelGGL(k_gs_chk_reduce, dim3(pass), dim3(BS), 0, ctx->stream, chk_part, nb, chk_dev);
+  SD_HIP(ctx, hipGetLastError());
+  return SD_OK;
+}
+// w = (w - alpha v_j) - beta_{j-1} v_{j-1}, then (vjm1 != null) the reference's repair of the v_{j-1} component it has just put back:
+// w -= dot(v_{j-1}, w) v_{j-1}.  n2_out: |w|^2 partials of the final w (column 0 of an [nb][8] list); upd_scratch: one more list.
+int sd_k_gs_update(sd_ctx *ctx, double *w, const double *vj, const double *vjm1, int64_t N, const double *alpha_part,
+                   const double *n2_prev, double *store_alpha, double *store_beta, double *n2_out, double *upd_scratch) {
+  const int nb = sd_k_gs_blocks(N);
+  hipLaunchKernelGGL(k_gs_update, dim3(nb), dim3(BS), 0, ctx->stream, w, vj, vjm1, N, alpha_part, nb, n2_prev, nb, store_alpha,
+                     store_beta, vjm1 ? upd_scratch : n2_out);
+  if (vjm1) hipLaunchKernelGGL(k_gs_correct, dim3(nb), dim3(BS), 0, ctx->stream, w, vjm1, N, upd_scratch, nb, n2_out);
+  SD_HIP(ctx, hipGetLastError());
+  return SD_OK;
+}
+int sd_k_gs_scale(sd_ctx *ctx, double *vnext, const double *w, int64_t N, const double *n2_part, double *store_beta) {
+  const int nb = sd_k_gs_blocks(N);
+  hipLaunchKernelGGL(k_gs_scale, dim3(std::min(nb * 2, 2048)), dim3(BS), 0, ctx->stream, vnext, w, N, n2_part, nb, store_beta);
   SD_HIP(ctx, hipGetLastError());
   return SD_OK;
 }

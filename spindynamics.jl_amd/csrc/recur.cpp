@@ -748,6 +748,94 @@ static int sd_lanczos_groundstate_impl(sd_ctx *ctx, const sd_model *m, int lanc_
   RC(sd_k_scale_div(ctx, V.p, V.p, N, nrm));                                             // :100,105
   std::vector<double> alpha(mm, 0.0), beta(mm, 0.0);
   int m_actual = mm;
+  // The reference's orthogonality check of step j (:142-153: dot(V[:,k], w/beta) for every k <= j) as the sequential loop
+  // would run it, from column k0 on: corrects w and beta[j-1] when a test fires.  Returns 1 on breakdown (beta < tol).
+  auto check_and_correct = [&](int j, double *wj, double *scratch_vec, int *broke) -> int {
+    double s[2];
+    std::vector<double> chk(j);
+    *broke = 0;
+    for (int k = 1; k <= j;) {
+      RC(sd_k_scale_div(ctx, scratch_vec, wj, N, beta[j - 1]));
+      RC(sd_k_mdot(ctx, V.p + N * (int64_t)(k - 1), N, j - k + 1, scratch_vec, N, chk.data()));
+      int hit = -1;
+      for (int q = 0; q < j - k + 1 && hit < 0; ++q)
+        if (std::fabs(chk[q]) > orth_tol) hit = k + q;
+      if (hit < 0) break;
+      double *vk = V.p + N * (int64_t)(hit - 1);
+      RC(sd_k_dot(ctx, 1, vk, wj, N, 4)); RC(sd_read_scalars(ctx, 4, 1, s));
+      RC(sd_k_sub2(ctx, wj, vk, nullptr, N, s[0], 0.0));
+      beta[j - 1] = norm_dev(op, wj, N, &rc); RC(rc);
+      if (beta[j - 1] < tol) { *broke = 1; break; }                                       // inner break only (:150)
+      k = hit + 1;
+    }
+    return SD_OK;
+  };
+  static const int gs_fused_env = getenv("SD_GS_FUSED") ? atoi(getenv("SD_GS_FUSED")) : 1;
+  if (ctx->gs_blocked && !ctx->user_apply && gs_fused_env && mm >= 2) {
+    // Passes that sum their producer's partial lists themselves (kernels_blas1.hip, k_gs_*): a step is the apply, one launch per
+    // block of 8 columns, the update and the normalising pass -- no reduction launches, alpha_j and beta_j stay on the device --
+    // and the orthogonality check of step j rides along with the Gram-Schmidt passes of step j + 1 (they read the same columns;
+    // w_j / beta_j is V[:,j+1] itself), which removes a sweep over all columns per step.  ONE host synchronisation per step, to
+    // look at the check (and beta) of the step before.  The one hit the reference's check loop finds on EVERY step -- the v_{j-1}
+    // component that :129 puts back after the re-orthogonalisation had removed it -- is repaired inside the
+    // update (k_gs_correct: w -= dot(v_{j-1}, w) v_{j-1}, then beta_j = norm(w), as :147-148).  If a check still fires -- orthogonality
+    // lost beyond orth_tol, which the full re-orthogonalisation does not let happen in practice -- the step before is run through
+    // the reference's loop itself and the current step is redone.
+    const int nb = sd_k_gs_blocks(N);
+    const size_t lst = (size_t)nb * 8;
+    DBuf w2, scr, lists, ab, chkd;
+    RC(w2.alloc(ctx, N));
+    RC(scr.alloc(ctx, (int64_t)((size_t)(mm / 8 + 4) * lst)));
+    RC(lists.alloc(ctx, (int64_t)(4 * lst)));                      // alpha partials | |w|^2 partials of the two latest steps | the update's pair
+    RC(ab.alloc(ctx, 2 * (int64_t)mm + 2)); RC(chkd.alloc(ctx, (int64_t)mm + 16));
+    SD_HIP(ctx, hipMemsetAsync(ab.p, 0, sizeof(double) * (2 * (size_t)mm + 2), ctx->stream));
+    double *d_al = ab.p, *d_be = ab.p + mm, *apart = lists.p;
+    auto n2list = [&](int j) { return lists.p + lst * (size_t)(1 + (j & 1)); };
+    std::vector<double> hchk(mm + 16), hb(2);
+    bool deferred = true;                 // false for the redo of a step whose predecessor was just checked the sequential way
+    int j = 1;
+    while (j <= mm) {
+      double *vj = V.p + N * (int64_t)(j - 1);
+      double *t = (j & 1) ? w.p : w2.p, *wprev = (j & 1) ? w2.p : w.p;     // w_{j-1} stays intact while step j runs
+      RC(plain_op(ctx, m, SD_F64, t, vj));                                                // :113
+      const bool chk_now = deferred && j >= 2;
+      RC(sd_k_gs_chain(ctx, t, V.p, N, j, N, chk_now ? vj : nullptr, scr.p, apart, chkd.p));   // :116-124 (+ the check of step j-1)
+      RC(sd_k_gs_update(ctx, t, vj, j == 1 ? nullptr : V.p + N * (int64_t)(j - 2), N, apart, n2list(j - 1), d_al + (j - 1),
+                        j == 1 ? nullptr : d_be + (j - 2), n2list(j), lists.p + 3 * lst));  // :127-129, the k = j-1 repair (:142-148), |w|^2
+      if (j < mm) RC(sd_k_gs_scale(ctx, V.p + N * (int64_t)j, t, N, n2list(j), d_be + (j - 1)));   // :133, :155
+      if (j >= 2) {
+        // the step before: beta_{j-1} (breakdown, :136-139) and its orthogonality check (:142-153)
+        SD_HIP(ctx, hipMemcpyAsync(hb.data(), d_be + (j - 2), sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        if (chk_now) SD_HIP(ctx, hipMemcpyAsync(hchk.data(), chkd.p, sizeof(double) * (size_t)(j - 1), hipMemcpyDeviceToHost, ctx->stream));
+        SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (deferred) beta[j - 2] = hb[0];
+        if (!(beta[j - 2] >= tol)) { m_actual = j - 1; break; }                            // (NaN counts as a breakdown)
+        bool fired = false;
+        if (chk_now)
+          for (int k = 0; k < j - 1 && !fired; ++k) fired = std::fabs(hchk[k]) > orth_tol;
+        if (fired) {
+          int broke = 0;
+          RC(check_and_correct(j - 1, wprev, t, &broke));
+          if (broke) { m_actual = j - 1; break; }
+          RC(sd_k_scale_div(ctx, vj, wprev, N, beta[j - 2]));                              // :155 with the corrected w, beta
+          // the device copy of |w_{j-1}|^2 (a one-entry list) and of beta_{j-1} follow the correction
+          std::vector<double> one(lst, 0.0); one[0] = beta[j - 2] * beta[j - 2];
+          SD_HIP(ctx, hipMemcpyAsync(n2list(j - 1), one.data(), sizeof(double) * lst, hipMemcpyHostToDevice, ctx->stream));
+          SD_HIP(ctx, hipMemcpyAsync(d_be + (j - 2), &beta[j - 2], sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+          SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+          deferred = false;
+          continue;                                                                        // redo step j on the corrected v_j
+        }
+      }
+      deferred = true;
+      ++j;
+    }
+    std::vector<double> host(2 * (size_t)mm);
+    SD_HIP(ctx, hipMemcpyAsync(host.data(), ab.p, sizeof(double) * host.size(), hipMemcpyDeviceToHost, ctx->stream));
+    SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < m_actual; ++k) alpha[k] = host[k];
+    for (int k = 0; k + 1 < m_actual; ++k) beta[k] = host[mm + k];
+  } else
   for (int j = 1; j <= mm; ++j) {
     double *vj = V.p + N * (int64_t)(j - 1);
     RC(plain_op(ctx, m, SD_F64, w.p, vj));                                                // :113

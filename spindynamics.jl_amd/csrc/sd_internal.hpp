@@ -262,6 +262,13 @@ int sd_k_lanczos_fold_scalars(sd_ctx *ctx, int form, const double *dot_dev, cons
                               double *store_bc);
 int sd_k_mgs_chain(sd_ctx *ctx, double *w, const double *V, int64_t ld, int ncols, int64_t N, int slot);   // MGS against V[:,0..ncols-2], then dot with V[:,ncols-1] -> d_scalars[slot]
 int sd_k_bgs_chain(sd_ctx *ctx, double *w, const double *V, int64_t ld, int ncols, int64_t N, int slot);   // the same in blocks of 8 columns (classical inside a block): ~half the passes over memory
+// lanczos_groundstate as passes that sum their producer's partial lists themselves (kernels_blas1.hip, "without reduction launches")
+int sd_k_gs_blocks(int64_t N);
+int sd_k_gs_chain(sd_ctx *ctx, double *w, const double *V, int64_t ld, int ncols, int64_t N, const double *y, double *scratch,
+                  double *alpha_part, double *chk_dev);
+int sd_k_gs_update(sd_ctx *ctx, double *w, const double *vj, const double *vjm1, int64_t N, const double *alpha_part,
+                   const double *n2_prev, double *store_alpha, double *store_beta, double *n2_out, double *upd_scratch);
+int sd_k_gs_scale(sd_ctx *ctx, double *vnext, const double *w, int64_t N, const double *n2_part, double *store_beta);
 int sd_k_mdot(sd_ctx *ctx, const double *V, int64_t ld, int ncols, const double *y, int64_t N, double *out_host);   // out[c] = V[:,c].y (real)
 int sd_read_scalars(sd_ctx *ctx, int slot, int count, double *out);
 int sd_k_scale_div(sd_ctx *ctx, double *y, const double *x, int64_t n, double d);      // y = x / d

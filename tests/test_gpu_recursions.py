@@ -541,6 +541,27 @@ def test_set_apply_belongs_to_the_context_and_dies_with_its_model(pkg):
     assert len(calls) == n and got == want
 
 
+def test_groundstate_deferred_orthogonality_check_and_its_fallback(pkg, O):
+    """lanczos_groundstate runs the reference's orthogonality check of step j (src/Lanczos.jl:142-153) together with the Gram-Schmidt
+    passes of step j + 1 and corrects the step before, the reference's way, when a check fires.  With the default tolerance the
+    check never fires; with orthogonalize_tol = 1e-18 it fires on every step (rounding-level overlaps), so every step takes the
+    correction-and-redo path: E0 and the vector must still agree with the oracle, which runs the reference's loop literally."""
+    for (L, nup, lm) in ((12, 6, 30), (14, 7, 41)):
+        m = pkg.XXZChain(L, Jz=0.9, nup=nup)
+        r = O.XXZChain(L, Jz=0.9, nup=nup)
+        x0 = np.random.default_rng(50 + L).standard_normal(m.N)
+        for otol in (1e-10, 1e-18):
+            E2, gs2 = O.lanczos_groundstate(r, x0, lanc_m=lm, orthogonalize_tol=otol)
+            E, gs = pkg.lanczos_groundstate(pkg.apply_H, m, lanc_m=lm, psi0=x0, orthogonalize_tol=otol)
+            assert abs(E - E2) <= 1e-10, (L, otol, E - E2)
+            assert min(np.abs(gs - gs2).max(), np.abs(gs + gs2).max()) <= 1e-6
+    # a start vector that is an exact eigenvector (uniform state at the Heisenberg point): beta_1 = 0 -> breakdown after one step,
+    # as the reference breaks (:136-139); the steps queued behind it are discarded
+    mh = pkg.XXZChain(12, nup=6)
+    E, gs = pkg.lanczos_groundstate(pkg.apply_H, mh, lanc_m=10, psi0=np.ones(mh.N))
+    assert abs(E - 11 / 4) <= 1e-12 and np.abs(np.abs(gs) - 1 / np.sqrt(mh.N)).max() <= 1e-12
+
+
 def test_blocked_gram_schmidt_chain_sizes(pkg, O):
     """lanczos_groundstate with the blocked re-orthogonalisation across the block boundaries (1, 8, 9, 16, 17, 25 columns) and
     an odd dimension (scalar tail of the 16-byte loop): E0 against the oracle and against the column-by-column chain."""
