@@ -103,6 +103,7 @@ __global__ __launch_bounds__(BLOCK, (NC == 2 ? SD_LB_C128 : SD_LB_F64)) void k_a
     if (ea.phi) ea.phi = (const double *)ea.phi + boff;
     if (ea.accv) ea.accv = (double *)ea.accv + boff;
     partials += 2 * (size_t)blockIdx.y * (size_t)dm.n_singles;
+    ea.negate = (ea.negate >> blockIdx.y) & 1;                 // a batch carries one negate bit per vector
   }
   const V *__restrict__ psi = reinterpret_cast<const V *>(psi_);
   const V *__restrict__ halo = reinterpret_cast<const V *>(ea.halo);

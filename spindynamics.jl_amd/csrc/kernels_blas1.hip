@@ -541,18 +541,7 @@ __global__ __launch_bounds__(BS) void k_lanczos_fold_p(double2 *__restrict__ t, 
   double s = 0.0, s1 = 0.0;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += stride) {
-    const double2 tt = t[i], cc = uc[i];
-    const double wx = tt.x / f.bc, wy = tt.y / f.bc, vx = cc.x / f.bc, vy = cc.y / f.bc;
-    double ux = 0.0, uy = 0.0;
-    if (HAVE_U) { const double2 pp = up[i]; ux = pp.x / f.bp; uy = pp.y / f.bp; }
-    double2 r;
-    if (FORM == 0) {
-      r.x = HAVE_U ? wx - (f.ar * vx + f.bc * ux) : wx - f.ar * vx;
-      r.y = HAVE_U ? wy - (f.ar * vy + f.bc * uy) : wy - f.ar * vy;
-    } else {
-      r.x = wx - f.ar * vx; r.y = wy - f.ar * vy;
-      if (HAVE_U) { r.x -= f.bc * ux; r.y -= f.bc * uy; }
-    }
+    const double2 r = fold_elem<FORM, HAVE_U>(t[i], uc[i], HAVE_U ? up[i] : make_double2(0.0, 0.0), f);
     t[i] = r;
     s += r.x * r.x + r.y * r.y;
   }
@@ -883,7 +872,7 @@ int sd_k_lanczos_fold(sd_ctx *ctx, double *t, const double *uc, const double *up
 }
 // launch-bound sizes (see k_lanczos_fold_p): `batch` vectors `bstride` elements apart; dotp: the apply's per-tile pairs (ndot per
 // vector), n2cp / n2pp: the per-block |w|^2 pairs of the two previous updates (nn2 per vector; null: normalised vector);
-// n2out receives *nb_out pairs per vector.  form 0 or 1.
+// n2out receives nb pairs per vector.  form 0, 1 or 2 (complex alpha: store_alpha receives (re, im)).
 int sd_k_lanczos_fold_p(sd_ctx *ctx, double *t, const double *uc, const double *up, int64_t N, int batch, int64_t bstride, int form,
                         const double *dotp, int ndot, const double *n2cp, const double *n2pp, int nn2, double *store_alpha,
                         double *store_bc, int64_t store_stride, double *n2out, int nb) {
@@ -894,6 +883,8 @@ int sd_k_lanczos_fold_p(sd_ctx *ctx, double *t, const double *uc, const double *
     case 1: k = k_lanczos_fold_p<0, true>; break;
     case 2: k = k_lanczos_fold_p<1, false>; break;
     case 3: k = k_lanczos_fold_p<1, true>; break;
+    case 4: k = k_lanczos_fold_p<2, false>; break;
+    case 5: k = k_lanczos_fold_p<2, true>; break;
     default: return sd_set_err(ctx, SD_EINTERNAL, "bad Lanczos update form");
   }
   hipLaunchKernelGGL(k, dim3((unsigned)nb, (unsigned)batch), dim3(BS), 0, ctx->stream, (double2 *)t, (const double2 *)uc,

@@ -634,6 +634,33 @@ static int energy_bounds_core(Op &op, int lanc_m, const void *psi0_a, const void
                               double *Emin, double *Emax) {
   sd_ctx *ctx = op.ctx;
   double lo, hi;
+  if (lanczos_fused_ok(op, 2)) {
+    // launch-bound sizes: the run on H (:258) and the run on -H (:261-267) are independent recursions -- one batch of two vectors,
+    // the second with the negated operator (bit 1 of the epilogue's negate mask); each sees the arithmetic of a run of its own
+    const int64_t N = op.n;
+    const int mm = (int)std::min<int64_t>(lanc_m, op.m->N);
+    if (mm < 1) return sd_set_err(ctx, SD_EARG, "lanc_m must be >= 1");
+    DBuf v; RC(v.alloc(ctx, 4 * N));
+    RC(start_vector_op(op, v.p, psi0_a, on_dev, 2 * N, seed));
+    RC(start_vector_op(op, v.p + 2 * N, psi0_b, on_dev, 2 * N, seed + 0x9E3779B97F4A7C15ULL));
+    int rc = 0;
+    for (int k = 0; k < 2; ++k) {
+      const double nrm = norm_dev(op, v.p + 2 * N * k, 2 * N, &rc); RC(rc);
+      RC(sd_k_scale_div(ctx, v.p + 2 * N * k, v.p + 2 * N * k, 2 * N, nrm));            // :40
+    }
+    std::vector<double> al, be;
+    RC(lanczos_fused(op, 2, v.p, mm, 0, /*negate mask: vector 1*/ 2, 1e-12, al, be));
+    for (int k = 0; k < 2; ++k) {
+      const double *a = al.data() + (size_t)k * mm, *b = be.data() + (size_t)k * mm;
+      int actual = mm;
+      for (int j = 1; j < mm; ++j)
+        if (!(b[j - 1] >= 1e-12)) { actual = j; break; }                                 // :66-70
+      std::vector<double> ev(actual);
+      if (sd_symtridiag_eig(actual, a, b, ev.data(), nullptr)) return sd_set_err(ctx, SD_EINTERNAL, "tridiagonal eigen-solver did not converge");
+      if (k == 0) *Emax = ev[actual - 1]; else *Emin = -ev[actual - 1];
+    }
+    return SD_OK;
+  }
   {
     DBuf v; RC(v.alloc(ctx, 2 * op.n));
     RC(start_vector_op(op, v.p, psi0_a, on_dev, 2 * op.n, seed));
@@ -945,7 +972,24 @@ static int krylov_evolve_core(Op &op, int dtype, const void *psi0, int64_t n, do
   SD_HIP(ctx, hipMemsetAsync(ab.p, 0, sizeof(double) * (5 * (size_t)kry_m + 2), ctx->stream));
   sd_epi_args ea;
   const double *n2c = nullptr, *n2p = nullptr;
-  for (int j = 1; j <= kry_m; ++j) {
+  const bool fused = lanczos_fused_ok(op, 1);          // launch-bound sizes: two launches per step (see lanczos_fused)
+  DBuf n2l;
+  const int nt = op.m->dm.n_singles, nbf = sd_k_lanczos_fold_blocks(n);
+  if (fused) { RC(n2l.alloc(ctx, 3 * 2 * (int64_t)nbf)); ea.no_reduce = 1; }
+  auto n2buf = [&](int j) { return n2l.p + (size_t)(j % 3) * 2 * (size_t)nbf; };
+  for (int j = 1; fused && j <= kry_m; ++j) {
+    double *t = w.p;
+    if (j < kry_m) { RC(V[j].alloc(ctx, 2 * n)); t = V[j].p; }
+    RC(op.apply(SD_C128, t, V[j - 1].p, SD_EPI_DOT, ea));                                 // per-tile pairs of <u|Hu> (re, im) -> ctx->d_partials
+    const double *pc = j > 1 ? n2buf(j - 1) : nullptr, *pp = j > 2 ? n2buf(j - 2) : nullptr;
+    if (j == kry_m) {
+      RC(sd_k_lanczos_fold_scalars_p(ctx, 1, 2, ctx->d_partials, nt, pc, nbf, d_al + 2 * (j - 1), j > 1 ? d_be + (j - 2) : nullptr, 0));
+      break;
+    }
+    RC(sd_k_lanczos_fold_p(ctx, t, V[j - 1].p, j > 1 ? V[j - 2].p : nullptr, n, 1, n, 2, ctx->d_partials, nt, pc, pp, nbf,
+                           d_al + 2 * (j - 1), j > 1 ? d_be + (j - 2) : nullptr, 0, n2buf(j), nbf));   // :156-161
+  }
+  for (int j = 1; !fused && j <= kry_m; ++j) {
     double *t = w.p;
     if (j < kry_m) { RC(V[j].alloc(ctx, 2 * n)); t = V[j].p; }
     RC(op.apply(SD_C128, t, V[j - 1].p, SD_EPI_DOT, ea));                                 // :153,155 -> d_scalars[0..1]

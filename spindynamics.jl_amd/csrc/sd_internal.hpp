@@ -213,7 +213,7 @@ struct sd_epi_args {
   const void *prev = nullptr;   // phi_prev / v_prev
   void *accv = nullptr;         // psi_t (CHEB)
   const void *phi = nullptr;    // KPM reference vector
-  int negate = 0;               // PLAIN / DOT: out = -(H psi)
+  int negate = 0;               // PLAIN / DOT: out = -(H psi); batched launches: bit k = vector k
   int stream_hint = 0;          // set by sd_launch_apply: bit 0 non-temporal stores of out, bit 1 non-temporal side streams (prev, phi, psi_t); env SD_STREAM_HINT
   double *sums_dst = nullptr;   // where the two reduced sums of a DOT / KPM / RESCALE_DOT epilogue go (device; null: ctx->d_scalars[0..1])
   const void *halo = nullptr;   // sharded plans: imported partner tiles (offsets >= n_local); null = halo follows psi's owned rows
