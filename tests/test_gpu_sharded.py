@@ -255,6 +255,14 @@ def test_rccl_communicator_selftest_one_rank(pkg):
         pkg.check(pkg.lib().sd_apply_dev(ctx.h, m.h, 2, out2.data_ptr(), psi.data_ptr(), m.N), ctx.h)
         torch.cuda.synchronize()
         assert torch.equal(out, out2)
+        # the routed exchange list is validated when it is installed: empty = back to the default; a peer outside the communicator,
+        # a send into the halo, a receive into the vector, a relay range beyond the relay buffer, descending batches are refused
+        from spindynamics_jl_amd import _lib
+        X = _lib.sd_xop
+        assert pkg.lib().sd_comm_set_exchange_ops(h, None, 0, 0) == _lib.SD_OK
+        for bad in ([X(0, 0, 0, 0, 0, 8)], [X(0, 1, 0, 0, 0, 8)], [X(0, -1, 1, 1, 0, 8)]):
+            arr = (X * len(bad))(*bad)
+            assert pkg.lib().sd_comm_set_exchange_ops(h, arr, len(bad), 0) == _lib.SD_EARG        # one rank: every peer is out of range or itself
     finally:
         pkg.lib().sd_comm_destroy(h)
 
