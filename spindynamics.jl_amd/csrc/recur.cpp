@@ -182,7 +182,6 @@ int lanczos_fused(Op &op, int Qb, double *u0, int mm, int form, int negate, doub
   sd_epi_args ea; ea.negate = negate; ea.batch = Qb; ea.bstride = N; ea.no_reduce = 1;
   double *ucur = u0, *uprev = vp.p, *t = wb.p;
   std::vector<double> peek;
-  int queued = mm;
   for (int j = 1; j <= mm; ++j) {
     ctx->n_applies += Qb - 1;
     RC(op.apply(SD_C128, t, ucur, SD_EPI_DOT, ea));                      // per-tile pairs of <u|Hu> -> ctx->d_partials
@@ -204,10 +203,9 @@ int lanczos_fused(Op &op, int Qb, double *u0, int mm, int form, int negate, doub
         for (int k = 0; k < j - 1; ++k) if (!(std::fabs(peek[(size_t)(srow * q) + mm + k]) >= tol)) { broke = true; break; }
         all_broke = broke;
       }
-      if (all_broke) { queued = j; break; }
+      if (all_broke) break;
     }
   }
-  (void)queued;
   std::vector<double> host((size_t)(srow * Qb));
   SD_HIP(ctx, hipMemcpyAsync(host.data(), ab.p, sizeof(double) * host.size(), hipMemcpyDeviceToHost, ctx->stream));
   SD_HIP(ctx, hipStreamSynchronize(ctx->stream));

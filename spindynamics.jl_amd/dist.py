@@ -7,10 +7,13 @@ recursion).  A hop on a prefix bond maps whole tiles onto whole tiles, so whole 
 
 Two ownership modes (csrc/basis.cpp):
   "range": contiguous basis-index ranges; a few contiguous slabs of psi itself are sent per peer.
-  "class" (default): popcount cells (k1, k2) of two nested site blocks cut into equal-weight runs; only two bonds can cross a
-      cut, so 3-4x fewer rows are imported (L=32: 0.15 / 0.50 / 0.74 per owned row at 2 / 4 / 8 ranks instead of 0.52 / 1.50 /
-      2.50); the owner packs the requested tiles into a send buffer and ONE message travels per (owner, receiver) pair.
-Transport: torch.distributed P2P ops, i.e. RCCL over xGMI on GPUs (backend "nccl") and gloo in the CPU tests.
+  "class" (default): ownership by the up-spin counts of nested site blocks (nested bisections for 2 / 4 / 8 ranks, runs of popcount
+      cells otherwise); only the bonds at block ends can cross a cut, so 3-4x fewer rows are imported (L=32: 0.15 / 0.41 / 0.73 per
+      owned row at 2 / 4 / 8 ranks instead of 0.52 / 1.50 / 2.50).  The tiles a peer needs form long contiguous runs of the owner's
+      vector and travel straight from it, one send per run (`packed` False); plans whose runs are short pack them into a send
+      buffer and ONE message travels per (owner, receiver) pair (`packed` True).
+Transport: the library's own RCCL communicator (default under an NCCL process group, csrc/comm.cpp) or torch.distributed P2P ops
+behind callbacks (gloo in the CPU tests and rehearsals); optional pipelined two-hop relays (relay_routes / relay_ops).
 """
 import ctypes as C
 import os
