@@ -357,14 +357,17 @@ class ShardedOperator:
         self.comm_kind, self.comm_note = None, ""     # which communicator comm() settled on ("rccl" / "torch"), and why not RCCL
         self._routes = None               # two-hop routes of the halo messages (SD_RELAY=1, popcount-cell ownership, >= 3 ranks)
 
-    def relay_plan(self, group=None):
+    def relay_plan(self, group=None, relay=None):
         """Routes of relay_routes for this operator's exchange, or None: built once, collectively, from every rank's receive
         list -- per (owner, receiver) pair the lengths of the segments the message consists of (one for a packed send buffer, one
-        per contiguous run when the runs travel straight from psi).  Cell ownership, at least three ranks."""
+        per contiguous run when the runs travel straight from psi).  Cell ownership, at least three ranks.  `relay` stands in
+        for the environment's SD_RELAY ("1": routes that pay, "2": forced) when given."""
         import os
+        if relay is None:
+            relay = os.environ.get("SD_RELAY", "0")
         if self._routes is None:
             self._routes = False
-            if os.environ.get("SD_RELAY", "0") not in ("", "0") and self.mode == "class" and self.world >= 3 \
+            if relay not in ("", "0") and self.mode == "class" and self.world >= 3 \
                     and self._exchange_fn is None:
                 import torch.distributed as dist
                 mine = {}
@@ -375,10 +378,19 @@ class ShardedOperator:
                 self._relay_runs = {(o, r): lst for r, d in enumerate(everyone) for o, lst in d.items()}
                 self._relay_M = {pr: sum(lst) for pr, lst in self._relay_runs.items()}
                 routes = relay_routes(self._relay_M, int(os.environ.get("SD_RELAY_CHUNKS", "8")),
-                                      int(os.environ.get("SD_RELAY_MIN", "65536")), force=os.environ.get("SD_RELAY") == "2")
+                                      int(os.environ.get("SD_RELAY_MIN", "65536")), force=relay == "2")
                 if any(k >= 0 for lst in routes.values() for (k, _u) in lst):
                     self._routes = routes
         return self._routes or None
+
+    def set_relay(self, routes):
+        """Switch the exchange of BOTH transports to `routes` (a relay_plan result) or, with None, back to the direct exchange:
+        the torch.distributed transport reads self._routes, the library's RCCL communicator gets the op list installed or removed.
+        Collective in the sense that every rank must make the same call."""
+        import os
+        self._routes = routes if routes is not None else False
+        if isinstance(self._comm, RcclComm):
+            self._comm.set_routes(self, routes, int(os.environ.get("SD_RELAY_BATCHES", "4")))
 
     def _relay_runs_of(self, o, r, lo, hi):
         """Lengths of the segments in which the elements [lo, hi) of message o -> r travel from their owner."""

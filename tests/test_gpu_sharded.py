@@ -298,6 +298,55 @@ def test_bench_starts_its_own_ranks_two_processes_one_gpu():
     assert line["config"]["path"].startswith("library") and lp["python_path_ms_per_step"] > 0
 
 
+def test_bench_tries_the_relays_after_the_direct_exchange_four_processes_one_gpu():
+    """`bench.py --gpus 4` measures the direct exchange first and then tries the two-hop relays (forced here: at four ranks no
+    route pays by itself): routed halo and H psi must equal the direct ones to the bit before the routed step is timed, and it
+    becomes the headline only when faster.  gloo backend, four ranks on this GPU; either outcome is a green run, the line must
+    say which."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SD_RELAY")}
+    env.update(SD_BENCH_BACKEND="gloo", SD_BENCH_RELAY_TRIAL="2", SD_RELAY_MIN="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--L", "24", "--steps", "4",
+                        "--warmup", "1"], cwd=root, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 4 and line["value"] > 0
+    trial = line["config"]["relay_trial"]
+    assert trial["status"].startswith("ok"), trial
+    assert trial["ms_per_step"] > 0 and trial["direct_ms_per_step"] > 0
+    routed_headline = "relays" in line["config"]["path"]
+    assert routed_headline == (trial["ms_per_step"] < trial["direct_ms_per_step"])
+    assert ("two-hop" in line["config"]["halo_routing"]) == routed_headline
+    assert abs(line["ms_per_step"] - (trial["ms_per_step"] if routed_headline else trial["direct_ms_per_step"])) < 1e-9
+
+
+def test_bench_relay_trial_that_hangs_leaves_the_direct_line_and_a_green_exit():
+    """The safety net of the relay trial: its watchdog (fired at once here) prints the line of the direct exchange measured before
+    it, marked as such, and every rank leaves with status 0 -- an optional leg cannot cost the measurement."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SD_RELAY")}
+    env.update(SD_BENCH_BACKEND="gloo", SD_BENCH_RELAY_TRIAL="2", SD_RELAY_MIN="0", SD_BENCH_RELAY_TIMEOUT="0.000001")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--L", "22", "--steps", "3",
+                        "--warmup", "1"], cwd=root, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 3 and line["value"] > 0
+    assert line["config"]["relay_trial"]["status"].startswith("timeout")
+    assert "relays" not in line["config"]["path"] and line["config"]["library_path"]["status"].startswith("ok")
+
+
 def test_bench_rccl_leg_runs_with_one_rank():
     """The library's own RCCL communicator with a 1-rank NCCL process group on this GPU: creation from a broadcast id, ring
     self-test, sd_apply_sharded on it compared bit for bit with the Python-issued step, a timed loop -- everything of the path
