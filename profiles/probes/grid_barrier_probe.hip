@@ -1,5 +1,5 @@
 // What does a grid-wide barrier cost on this chip?  (decides whether a whole launch-bound recursion can live in ONE launch)
-//   hipcc --offload-arch=gfx950 -O3 -o gpurun_out/grid_barrier_probe profiles/grid_barrier_probe.hip && gpurun_out/grid_barrier_probe
+//   hipcc --offload-arch=gfx950 -O3 -o gpurun_out/grid_barrier_probe profiles/probes/grid_barrier_probe.hip && gpurun_out/grid_barrier_probe
 // G workgroups of 256 threads meet K times at a counter in device memory (release add, acquire spin, bounded); between two
 // barriers every workgroup writes one line and reads its neighbour's (so the numbers include making data visible across XCDs).
 #include <hip/hip_runtime.h>
