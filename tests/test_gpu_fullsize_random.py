@@ -1,0 +1,176 @@
+"""Bit-exact row samples of H|psi> on a RANDOM vector at BASELINE's full sizes, where the C oracle cannot follow (its states[] and
+hash map alone are 23 GB at L=32).
+
+The reference's row loop (src/Hamiltonian.jl:211-273) needs, for one row, nothing but the row's configuration and psi at <= L-1 partner
+rows.  For a few ten thousand sampled rows -- the first and last rows, rows around tile boundaries, random rows -- this test restates
+that loop in numpy on its own: configuration from the row index by the combinadic unranking of the lexicographic-combination order
+(src/Basis.jl:37-53), the diagonal as the reference's sequential sum (fields i = 1..L, then zz in list order), the
+partner index by ranking the flipped configuration, psi at the partner rows gathered from the device vector, `value += J * psi'` in
+list order.  Nothing of the library takes part in the expected values except the random vector itself; every sampled row must match the
+device result to the bit (real and imaginary parts as separate IEEE doubles; the reference has no fused multiply-add, and the kernel's
+fma for power-of-two amplitudes is exact)."""
+from math import comb
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def unrank(rows, L, nup):
+    """configurations (uint64, site i = bit i-1) of 0-based rows in the reference order: site 1 up first"""
+    idx = rows.astype(np.int64).copy()
+    r = np.full(idx.shape, nup, dtype=np.int64)
+    s = np.zeros(idx.shape, dtype=np.uint64)
+    table = np.array([[comb(n, k) for k in range(nup + 1)] for n in range(L + 1)], dtype=np.int64)
+    for k in range(1, L + 1):
+        c = np.where(r > 0, table[L - k, np.maximum(r - 1, 0)], 0)
+        up = (r > 0) & (idx < c)
+        s |= np.where(up, np.uint64(1) << np.uint64(k - 1), np.uint64(0))
+        idx = np.where(up | (r == 0), idx, idx - c)
+        r = r - up
+    assert (r == 0).all()
+    return s
+
+
+def rank(s, L, nup):
+    idx = np.zeros(s.shape, dtype=np.int64)
+    r = np.full(s.shape, nup, dtype=np.int64)
+    table = np.array([[comb(n, k) for k in range(nup + 1)] for n in range(L + 1)], dtype=np.int64)
+    for k in range(1, L + 1):
+        bit = ((s >> np.uint64(k - 1)) & np.uint64(1)).astype(bool)
+        add = np.where(~bit & (r > 0), table[L - k, np.maximum(r - 1, 0)], 0)
+        idx += add
+        r = r - bit
+    assert (r == 0).all()
+    return idx
+
+
+def sample_rows(model, n_random, seed):
+    N = model.N
+    rng = np.random.default_rng(seed)
+    parts = [np.arange(0, min(N, 2048)), np.arange(max(0, N - 2048), N), rng.integers(0, N, n_random)]
+    lb, gb, ln = model.local_tiles()                      # tile boundaries of the device plan: rows on both sides of a few hundred of them
+    pick = rng.choice(len(gb), size=min(len(gb), 300), replace=False)
+    for t in pick:
+        parts.append(np.arange(max(0, gb[t] - 3), min(N, gb[t] + 3)))
+    return np.unique(np.concatenate(parts).astype(np.int64))
+
+
+CASES = [
+    # L, nup, kwargs, dtype, random rows
+    (32, 16, {}, "c128", 20000),                                                     # the headline workload
+    (32, 16, {}, "f64", 20000),
+    (30, 15, {"Jxy": 0.7, "Jz": -0.4, "hz": 0.3}, "c128", 12000),                    # amplitudes that are no powers of two, fields
+    (28, 14, {"boundary": "periodic"}, "c128", 12000),                               # the wrap bond (L, 1)
+    (28, 12, {"Jz": 0.37, "boundary": "periodic"}, "f64", 12000),
+    (34, 17, {}, "f64", 12000),                                                      # rows past 2^31
+]
+
+
+@pytest.mark.parametrize("L,nup,kw,dtype,n_random", CASES)
+def test_random_vector_sampled_rows_bit_exact_full_size(pkg, L, nup, kw, dtype, n_random):
+    import torch
+    model = pkg.XXZChain(L, nup=nup, **kw)
+    N = model.N
+    esz = 16 if dtype == "c128" else 8
+    free, _ = torch.cuda.mem_get_info()
+    if free < 2 * esz * N + (3 << 30):
+        pytest.skip("not enough device memory")
+    tdt = torch.complex128 if dtype == "c128" else torch.float64
+    psi = torch.empty(N, dtype=tdt, device="cuda")
+    model.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    pkg.check(pkg.lib().sd_fill_randn_dev(model.ctx.h, psi.data_ptr(), (2 if dtype == "c128" else 1) * N, 20260821, 0), model.ctx.h)
+    out = torch.empty_like(psi)
+    pkg.apply_H(out, psi, model)
+    torch.cuda.synchronize()
+
+    rows = sample_rows(model, n_random, seed=L * 1000 + nup)
+    s = unrank(rows, L, nup)
+    assert (rank(s, L, nup) == rows).all()                                             # the two restatements agree with each other
+    Jxy, Jz, hz = kw.get("Jxy", 1.0), kw.get("Jz", 1.0), kw.get("hz", 0.0)
+    bonds = [(i, i + 1) for i in range(1, L)]
+    if kw.get("boundary") == "periodic" and L > 2:
+        bonds.append((L, 1))                                                           # src/SpinModel.jl:74-78
+    hop = Jxy / 2                                                                      # src/SpinModel.jl:71
+    sz = lambda site: np.where((s >> np.uint64(site - 1)) & np.uint64(1), 0.5, -0.5)   # noqa: E731
+
+    d = np.zeros(len(rows))
+    for i in range(1, L + 1):                                                          # src/Hamiltonian.jl:228-233
+        d = d + hz * sz(i)
+    for (i, j) in bonds:                                                               # :235-241
+        d = d + (Jz * sz(i)) * sz(j)
+
+    def gather(idx):
+        v = psi[torch.from_numpy(idx).cuda()].cpu().numpy()
+        return (v.real.copy(), v.imag.copy()) if dtype == "c128" else (v.copy(), None)
+
+    own_re, own_im = gather(rows)
+    val_re = d * own_re                                                                # :243
+    val_im = d * own_im if own_im is not None else None
+    for (i, j) in bonds:                                                               # :248-267
+        bi = (s >> np.uint64(i - 1)) & np.uint64(1)
+        bj = (s >> np.uint64(j - 1)) & np.uint64(1)
+        fl = bi != bj
+        if not fl.any():
+            continue
+        s2 = s[fl] ^ ((np.uint64(1) << np.uint64(i - 1)) | (np.uint64(1) << np.uint64(j - 1)))
+        p_re, p_im = gather(rank(s2, L, nup))
+        val_re[fl] = val_re[fl] + hop * p_re
+        if val_im is not None:
+            val_im[fl] = val_im[fl] + hop * p_im
+
+    got = out[torch.from_numpy(rows).cuda()].cpu().numpy()
+    if dtype == "c128":
+        assert np.array_equal(got.real, val_re) and np.array_equal(got.imag, val_im)
+    else:
+        assert np.array_equal(got, val_re)
+    assert np.isfinite(val_re).all() and np.abs(val_re).max() > 0.1                    # a real comparison, not zeros against zeros
+
+
+@pytest.mark.parametrize("world,mode,rank", [(8, "class", 2), (8, "class", 5), (8, "range", 3), (4, "class", 1), (2, "class", 1)])
+def test_one_rank_of_the_sharded_L32_apply_on_a_random_vector_equals_the_unsharded_rows(pkg, world, mode, rank):
+    """BASELINE's sharded workload (L=32 over 2 / 4 / 8 ranks) on ONE GPU, one receiving rank at a time, on the random vector of
+    bench.py: every peer's shard is materialised in turn (its owned rows of the global vector, packed by the HIP pack kernel where
+    the plan packs), its send slabs are copied into the receiver's halo exactly where a real exchange would put them, and the
+    receiver's sharded apply (interior launch, then boundary launch) must equal the rows it owns of the unsharded H psi, bit for
+    bit, all of them.  The unsharded apply itself is pinned row by row above."""
+    import torch
+    L, nup = 32, 16
+    full = pkg.XXZChain(L, nup=nup)
+    N = full.N
+    free, _ = torch.cuda.mem_get_info()
+    if free < 2 * 16 * N + (12 << 30):
+        pytest.skip("not enough device memory")
+    fop = pkg.ShardedOperator(full, 0, 1)
+    x = fop.fill_randn(fop.empty(torch.complex128, "cuda"), 20260821)
+    y = torch.empty_like(x)
+    pkg.apply_H(y, x, full)
+
+    m = pkg.XXZChain(L, nup=nup)
+    op = pkg.ShardedOperator(m, rank, world, mode=mode)
+    rows = torch.from_numpy(m.local_rows()).cuda()
+    mine = x[rows]
+    halo = op.halo(mine)
+    halo.fill_(float("nan"))
+    peers = sorted({s[0] for s in op.recv_slabs})
+    assert peers and rank not in peers
+    for q in peers:
+        mq = pkg.XXZChain(L, nup=nup)
+        oq = pkg.ShardedOperator(mq, q, world, mode=mode)
+        xq = x[torch.from_numpy(mq.local_rows()).cuda()]
+        src = oq.pack(xq) if oq.packed else xq
+        sends = [s for s in oq.send_slabs if s[0] == rank]
+        recvs = [s for s in op.recv_slabs if s[0] == q]
+        assert len(sends) == len(recvs)
+        for (_p, so, cnt, _g), (_p2, ro, cnt2, _g2) in zip(sends, recvs):
+            assert cnt == cnt2
+            halo[ro - op.n_local:ro - op.n_local + cnt] = src[so:so + cnt]
+        del xq, src, oq, mq
+    assert not bool(torch.isnan(halo.real).any())                       # every halo element was delivered
+    out = torch.full_like(mine, float("nan"))
+    op._launch(out, mine, halo, 0, part=1)
+    op._launch(out, mine, halo, 0, part=2)
+    torch.cuda.synchronize()
+    assert bool(torch.equal(out, y[rows]))
+    assert op.n_halo > 0 and (op.n_interior_tiles > 0 or mode == "range")      # (an inner index range of eight has no interior tile)
