@@ -68,24 +68,10 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("L,nup,kw,dtype,n_random", CASES)
-def test_random_vector_sampled_rows_bit_exact_full_size(pkg, L, nup, kw, dtype, n_random):
+def reference_rows(psi, rows, L, nup, kw, dtype):
+    """(own, H psi) at `rows` by the reference's row loop in numpy, real and imaginary parts as separate float64 arrays
+    (imaginary None for Float64); psi is the device vector, read only at the rows and their partner rows."""
     import torch
-    model = pkg.XXZChain(L, nup=nup, **kw)
-    N = model.N
-    esz = 16 if dtype == "c128" else 8
-    free, _ = torch.cuda.mem_get_info()
-    if free < 2 * esz * N + (3 << 30):
-        pytest.skip("not enough device memory")
-    tdt = torch.complex128 if dtype == "c128" else torch.float64
-    psi = torch.empty(N, dtype=tdt, device="cuda")
-    model.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-    pkg.check(pkg.lib().sd_fill_randn_dev(model.ctx.h, psi.data_ptr(), (2 if dtype == "c128" else 1) * N, 20260821, 0), model.ctx.h)
-    out = torch.empty_like(psi)
-    pkg.apply_H(out, psi, model)
-    torch.cuda.synchronize()
-
-    rows = sample_rows(model, n_random, seed=L * 1000 + nup)
     s = unrank(rows, L, nup)
     assert (rank(s, L, nup) == rows).all()                                             # the two restatements agree with each other
     Jxy, Jz, hz = kw.get("Jxy", 1.0), kw.get("Jz", 1.0), kw.get("hz", 0.0)
@@ -119,13 +105,76 @@ def test_random_vector_sampled_rows_bit_exact_full_size(pkg, L, nup, kw, dtype, 
         val_re[fl] = val_re[fl] + hop * p_re
         if val_im is not None:
             val_im[fl] = val_im[fl] + hop * p_im
+    return own_re, own_im, val_re, val_im
 
+
+def random_vector(pkg, model, N, dtype, seed):
+    import torch
+    tdt = torch.complex128 if dtype == "c128" else torch.float64
+    psi = torch.empty(N, dtype=tdt, device="cuda")
+    model.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    pkg.check(pkg.lib().sd_fill_randn_dev(model.ctx.h, psi.data_ptr(), (2 if dtype == "c128" else 1) * N, seed, 0), model.ctx.h)
+    return psi
+
+
+@pytest.mark.parametrize("L,nup,kw,dtype,n_random", CASES)
+def test_random_vector_sampled_rows_bit_exact_full_size(pkg, L, nup, kw, dtype, n_random):
+    import torch
+    model = pkg.XXZChain(L, nup=nup, **kw)
+    N = model.N
+    esz = 16 if dtype == "c128" else 8
+    free, _ = torch.cuda.mem_get_info()
+    if free < 2 * esz * N + (3 << 30):
+        pytest.skip("not enough device memory")
+    psi = random_vector(pkg, model, N, dtype, 20260821)
+    out = torch.empty_like(psi)
+    pkg.apply_H(out, psi, model)
+    torch.cuda.synchronize()
+    rows = sample_rows(model, n_random, seed=L * 1000 + nup)
+    _own_re, _own_im, val_re, val_im = reference_rows(psi, rows, L, nup, kw, dtype)
     got = out[torch.from_numpy(rows).cuda()].cpu().numpy()
     if dtype == "c128":
         assert np.array_equal(got.real, val_re) and np.array_equal(got.imag, val_im)
     else:
         assert np.array_equal(got, val_re)
     assert np.isfinite(val_re).all() and np.abs(val_re).max() > 0.1                    # a real comparison, not zeros against zeros
+
+
+def test_fused_rescale_and_chebyshev_term_sampled_rows_bit_exact_at_L32(pkg):
+    """The fused stores of the recursions on the headline workload, random vectors, sampled rows, to the bit:
+    apply_rescaled_H! = (H psi - b psi) / a with a true division (src/Hamiltonian.jl:286-301), and one Chebyshev term
+    phi_next = 2 H~ phi_curr - phi_prev; psi_t += c phi_next (src/TimeEvolution/Chebyshev.jl:110-121) with Julia's complex product."""
+    import torch
+    L, nup, kw = 32, 16, {}
+    model = pkg.XXZChain(L, nup=nup)
+    N = model.N
+    free, _ = torch.cuda.mem_get_info()
+    if free < 5 * 16 * N + (3 << 30):
+        pytest.skip("not enough device memory")
+    a, b, c = 8.3172, -2.71, complex(0.3125, -0.77)
+    phi = random_vector(pkg, model, N, "c128", 11)
+    prev = random_vector(pkg, model, N, "c128", 12)
+    psit = random_vector(pkg, model, N, "c128", 13)
+    rows = sample_rows(model, 12000, seed=77)
+    tr = torch.from_numpy(rows).cuda()
+    own_re, own_im, val_re, val_im = reference_rows(phi, rows, L, nup, kw, "c128")
+    prev_s, psit_s = prev[tr].cpu().numpy(), psit[tr].cpu().numpy()
+    out = torch.empty_like(phi)
+
+    pkg.apply_rescaled_H(out, phi, pkg.apply_H, model, a, b)
+    got = out[tr].cpu().numpy()
+    r_re, r_im = (val_re - b * own_re) / a, (val_im - b * own_im) / a
+    assert np.array_equal(got.real, r_re) and np.array_equal(got.imag, r_im)
+
+    pkg.cheb_step(out, phi, prev, psit, model, a, b, c)
+    torch.cuda.synchronize()
+    o_re, o_im = 2.0 * r_re - prev_s.real, 2.0 * r_im - prev_s.imag
+    got = out[tr].cpu().numpy()
+    assert np.array_equal(got.real, o_re) and np.array_equal(got.imag, o_im)
+    t_re = psit_s.real + (c.real * o_re - c.imag * o_im)
+    t_im = psit_s.imag + (c.real * o_im + c.imag * o_re)
+    got = psit[tr].cpu().numpy()
+    assert np.array_equal(got.real, t_re) and np.array_equal(got.imag, t_im)
 
 
 @pytest.mark.parametrize("world,mode,rank", [(8, "class", 2), (8, "class", 5), (8, "range", 3), (4, "class", 1), (2, "class", 1)])
