@@ -65,6 +65,7 @@ CASES = [
     (28, 14, {"boundary": "periodic"}, "c128", 12000),                               # the wrap bond (L, 1)
     (28, 12, {"Jz": 0.37, "boundary": "periodic"}, "f64", 12000),
     (34, 17, {}, "f64", 12000),                                                      # rows past 2^31
+    (36, 18, {}, "f64", 8000),                                                       # config 5's sector whole on one GPU: N = 9.08e9 rows, past 2^32
 ]
 
 
