@@ -520,6 +520,30 @@ __device__ __forceinline__ void sum_list(const double *__restrict__ p, int n, do
   if (threadIdx.x == 0) { bc[0] = a; bc[1] = b; }
   __syncthreads();
 }
+// the three lists of a fold pass in ONE sweep: <u|t> pairs, |u_cur|^2 and |u_prev|^2 (first components; the seconds are zero) --
+// per list the same thread-local order and the same tree as sum_list, i.e. the same bits, with three barriers instead of nine
+__device__ __forceinline__ void sum_lists3(const double *__restrict__ pd, int nd, const double *__restrict__ pc,
+                                           const double *__restrict__ pp, int nn, double *red /* 64 doubles LDS */,
+                                           double *sc /* 6 doubles LDS */) {
+  double a = 0.0, b = 0.0, c = 0.0, d = 0.0;
+  for (int i = threadIdx.x; i < nd; i += blockDim.x) { a += pd[2 * i]; b += pd[2 * i + 1]; }
+  if (pc) for (int i = threadIdx.x; i < nn; i += blockDim.x) c += pc[2 * i];
+  if (pp) for (int i = threadIdx.x; i < nn; i += blockDim.x) d += pp[2 * i];
+  for (int off = 32; off > 0; off >>= 1) {
+    a += __shfl_down(a, off, 64); b += __shfl_down(b, off, 64);
+    c += __shfl_down(c, off, 64); d += __shfl_down(d, off, 64);
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if (lane == 0) { red[4 * wv] = a; red[4 * wv + 1] = b; red[4 * wv + 2] = c; red[4 * wv + 3] = d; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double x = 0.0, y = 0.0, z = 0.0, w = 0.0;
+    for (int k = 0; k < nw; ++k) { x += red[4 * k]; y += red[4 * k + 1]; z += red[4 * k + 2]; w += red[4 * k + 3]; }
+    sc[0] = x; sc[1] = y; sc[2] = z; sc[3] = 0.0; sc[4] = w; sc[5] = 0.0;
+  }
+  __syncthreads();
+}
 template <int FORM, bool HAVE_U>
 __global__ __launch_bounds__(BS) void k_lanczos_fold_p(double2 *__restrict__ t, const double2 *__restrict__ uc,
                                                        const double2 *__restrict__ up, int64_t N, int64_t bstride,
@@ -527,14 +551,13 @@ __global__ __launch_bounds__(BS) void k_lanczos_fold_p(double2 *__restrict__ t, 
                                                        const double *__restrict__ n2cp, const double *__restrict__ n2pp, int nn2,
                                                        double *__restrict__ store_alpha, double *__restrict__ store_bc,
                                                        int64_t store_stride, double *__restrict__ n2out) {
-  __shared__ double red[32];
+  __shared__ double red[64];
   __shared__ double sc[6];
   const int q = blockIdx.y;
   t += (int64_t)q * bstride; uc += (int64_t)q * bstride;
   if (HAVE_U) up += (int64_t)q * bstride;
-  sum_list(dotp + 2 * (size_t)ndot * q, ndot, red, sc);
-  if (n2cp) sum_list(n2cp + 2 * (size_t)nn2 * q, nn2, red, sc + 2);
-  if (n2pp) sum_list(n2pp + 2 * (size_t)nn2 * q, nn2, red, sc + 4);
+  sum_lists3(dotp + 2 * (size_t)ndot * q, ndot, n2cp ? n2cp + 2 * (size_t)nn2 * q : nullptr, n2pp ? n2pp + 2 * (size_t)nn2 * q : nullptr,
+             nn2, red, sc);
   const FoldScalars f = fold_resolve(sc, n2cp ? sc + 2 : nullptr, n2pp ? sc + 4 : nullptr, FORM,
                                      store_alpha ? store_alpha + (int64_t)q * store_stride : nullptr,
                                      store_bc ? store_bc + (int64_t)q * store_stride : nullptr, blockIdx.x == 0 && threadIdx.x == 0);
