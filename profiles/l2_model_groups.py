@@ -1,164 +1,80 @@
-#!/usr/bin/env python3
-"""Offline model of one XCD's L2 for the register-group apply kernel (experiment tool, CPU only; companion of l2_model.py).
+"""Would LDS orbit groups cut the fabric bytes?  (CPU-only model, extends profiles/l2_model.py)
 
-Work unit = GROUP of 2^f tiles (prefix configurations of sites 1..p, p = L - LS) related by the first f flippable odd
-prefix bonds.  A group reads every member tile once (own rows, held in registers) and, per member and per flippable
-NON-generator prefix bond, the whole partner tile; plus the straddling half tile.  Groups are dealt to the 8 XCDs by
-super-orbits (the next FO2 flippable odd bonds), an XCD keeps W groups in flight, a group's reads are spread over its
-lifetime in bond order.  The L2 is a byte-capacity LRU over half-tiles.
+Idea: one workgroup holds the 2^g tiles of a sub-orbit (g disjoint flippable prefix bonds) in LDS, so that g of a row's ~10 far reads become
+LDS reads -- every included bond is flippable for every tile of the group, unlike two more suffix sites (x4 LDS for one read).
+Answer (python profiles/l2_model_groups.py 28): requests 148 -> 117 (g=2) -> 103 B/row (g=3), but L2 MISSES 94 -> 91.5 -> 86.5 B/row: the reads
+that move into LDS are exactly the ones the orbit order already serves from L2.  3-8 % fewer fabric bytes for 4-8x the LDS per workgroup
+(1-2 workgroups per CU).  Not built."""
+import os, sys
+sys.argv = [sys.argv[0], sys.argv[1] if len(sys.argv) > 1 else "28", "lex"]
+exec(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'l2_model.py')).read().split('print(f"L={L}')[0])
 
-usage: LS=10 F=4 W=64 FO2=2 python profiles/l2_model_groups.py [L]
-"""
-import os
-import sys
-from collections import OrderedDict
-from math import comb
+def group_queues(tiles, FO, g):
+    """orbit order; consecutive 2^g members (the first g generators) form one workgroup's group"""
+    first, keys = {}, []
+    for P in tiles:
+        C0, mem = canon(P, FO, False)
+        if C0 not in first:
+            first[C0] = len(first)
+        keys.append((first[C0], mem >> g, mem & ((1 << g) - 1)))
+    idx = sorted(range(len(tiles)), key=lambda k: keys[k])
+    q = [[] for _ in range(8)]
+    o, k = 0, 0
+    while k < len(idx):
+        e = k
+        while e < len(idx) and keys[idx[e]][0] == keys[idx[k]][0]:
+            e += 1
+        # split the orbit into groups
+        grp, cur = [], None
+        for i in idx[k:e]:
+            gk = keys[i][1]
+            if gk != cur:
+                grp.append([]); cur = gk
+            grp[-1].append(tiles[i])
+        q[o % 8].extend(grp)
+        o += 1
+        k = e
+    return q
 
-L = int(sys.argv[1]) if len(sys.argv) > 1 else 28
-LS, nup = int(os.environ.get("LS", "10")), L // 2
-p = L - LS
-F = int(os.environ.get("F", "4"))
-FO2 = int(os.environ.get("FO2", "2"))
-CAP = int(float(os.environ.get("CAP_MIB", "4")) * (1 << 20))
-W = int(os.environ.get("W", "64"))
-ES = 16
-
-
-def tile_len(P):
-    t = nup - bin(P).count("1")
-    return comb(LS, t) if 0 <= t <= LS else 0
-
-
-def n_up_first(P):
-    t = nup - bin(P).count("1")
-    return comb(LS - 1, t - 1) if t >= 1 else 0
-
-
-def gens_of(P, nmax):
-    g = []
-    b = 1
-    while b + 1 <= p and len(g) < nmax:
-        if ((P >> (b - 1)) ^ (P >> b)) & 1:
-            g.append(b)
-        b += 2
-    return g
-
-
-def canon(P, gens):
-    C0, mem = P, 0
-    for k, b in enumerate(gens):
-        if not (P >> (b - 1)) & 1:
-            C0 ^= 3 << (b - 1)
-            mem |= 1 << k
-    return C0, mem
-
-
-# groups: canonical representative with exactly F generators (fewer: smaller groups, same treatment)
-groups = {}
-for P in range(1 << p):
-    if tile_len(P) == 0:
-        continue
-    g = gens_of(P, F)
-    C0, mem = canon(P, g)
-    groups.setdefault((C0, tuple(g)), []).append(P)
-glist = sorted(groups.items(), key=lambda kv: kv[0][0])
-
-# super-orbit key: canonical rep under the next FO2 flippable odd bonds after the group's generators
-def super_key(C0, g):
-    allg = gens_of(C0, F + FO2)
-    extra = allg[len(g):]
-    S0, mem = canon(C0, extra)
-    return S0, mem
-
-first = {}
-keyed = []
-for (C0, g), members in glist:
-    S0, mem = super_key(C0, g)
-    if S0 not in first:
-        first[S0] = len(first)
-    keyed.append((first[S0], mem, C0, g, members))
-keyed.sort(key=lambda r: (r[0], r[1]))
-queues = [[] for _ in range(8)]
-o, k = 0, 0
-CH = int(os.environ.get("CH", "0"))     # > 0: runs of CH lexicographically consecutive groups per XCD instead of super-orbits
-if CH > 0:
-    keyed.sort(key=lambda r: r[2])
-    # bit-reversed representative: consecutive keys differ in the LOWEST prefix sites (neighbouring tiles in memory)
-    def brev(P):
-        return int(format(P, "0%db" % p)[::-1], 2)
-    keyed.sort(key=lambda r: brev(r[2]) if os.environ.get("BREV") else r[2])
-    for c in range(0, len(keyed), CH):
-        queues[(c // CH) % 8].extend(keyed[c:c + CH])
-    k = len(keyed)
-while k < len(keyed):
-    e = k
-    while e < len(keyed) and keyed[e][0] == keyed[k][0]:
-        e += 1
-    queues[o % 8].extend(keyed[k:e])
-    o += 1
-    k = e
-
-
-def events(queue):
+def events_group(queue, Wg):
     ev = []
     life = 1.0
-    for j, (_, _, C0, g, members) in enumerate(queue):
-        t0 = j * life / W
-        gset = set(g)
-        for P in members:
-            ev.append((t0, (P, 0), n_up_first(P) * ES))
-            ev.append((t0, (P, 1), (tile_len(P) - n_up_first(P)) * ES))
-        # far reads in bond order, spread over (0.1 .. 0.7) of the lifetime
-        for b in range(1, p + 1):
-            tb = t0 + life * (0.1 + 0.6 * b / p)
-            for P in members:
-                if b <= p - 1:
-                    if b in gset:
-                        continue
-                    if ((P >> (b - 1)) ^ (P >> b)) & 1:
-                        Q = P ^ (3 << (b - 1))
-                        ev.append((tb, (Q, 0), n_up_first(Q) * ES))
-                        ev.append((tb, (Q, 1), (tile_len(Q) - n_up_first(Q)) * ES))
-                else:
-                    Q = P ^ (1 << (p - 1))
-                    if tile_len(Q) > 0:
-                        half = 0 if (P >> (p - 1)) & 1 else 1
-                        sz = n_up_first(Q) * ES if half == 0 else (tile_len(Q) - n_up_first(Q)) * ES
-                        if sz > 0:
-                            ev.append((tb, (Q, half), sz))
+    for j, G in enumerate(queue):
+        t0 = j * life / Wg
+        S = set(G)
+        reads = []
+        for P in G:
+            reads.append(((P, 0), n_up_first(P) * 16)); reads.append(((P, 1), (tile_len(P) - n_up_first(P)) * 16))
+        far = []
+        for P in G:
+            for b in range(1, p):
+                if ((P >> (b - 1)) ^ (P >> b)) & 1:
+                    Q = P ^ (3 << (b - 1))
+                    if Q in S: continue
+                    far.append(((Q, 0), n_up_first(Q) * 16)); far.append(((Q, 1), (tile_len(Q) - n_up_first(Q)) * 16))
+            Q = P ^ (1 << (p - 1))
+            if tile_len(Q) > 0:
+                half = 0 if (P >> (p - 1)) & 1 else 1
+                sz = n_up_first(Q) * 16 if half == 0 else (tile_len(Q) - n_up_first(Q)) * 16
+                if sz > 0: far.append(((Q, half), sz))
+        allr = reads + far
+        n = len(allr)
+        for k_, (obj, sz) in enumerate(allr):
+            ev.append((t0 + life * k_ / (n + 1), obj, sz))
     return ev
 
+def run(q, Wg, label):
+    tot_req = tot_miss = rows = 0
+    for x in (0, 3):
+        ev = events_group(q[x], Wg); ev.sort(key=lambda e: e[0])
+        l2 = LRU(CAP)
+        for _, obj, sz in ev:
+            tot_req += sz
+            if not l2.access(obj, sz): tot_miss += sz
+        rows += sum(tile_len(P) for G in q[x] for P in G)
+    print(f"{label:28s} requests {tot_req/rows:6.1f} B/row  L2 misses {tot_miss/rows:6.1f} B/row  hit {1-tot_miss/tot_req:.3f}  (+16 B/row write)", flush=True)
 
-class LRU:
-    def __init__(self, cap):
-        self.cap, self.used, self.d = cap, 0, OrderedDict()
-
-    def access(self, obj, sz):
-        if obj in self.d:
-            self.d.move_to_end(obj)
-            return True
-        self.d[obj] = sz
-        self.used += sz
-        while self.used > self.cap:
-            _, s2 = self.d.popitem(last=False)
-            self.used -= s2
-        return False
-
-
-tot_req = tot_miss = rows = 0
-for x in (0, 3):
-    ev = events(queues[x])
-    ev.sort(key=lambda e: e[0])
-    l2 = LRU(CAP)
-    for _, obj, sz in ev:
-        if sz == 0:
-            continue
-        tot_req += sz
-        if not l2.access(obj, sz):
-            tot_miss += sz
-    rows += sum(tile_len(P) for r in queues[x] for P in r[4])
-sizes = {}
-for r in keyed:
-    sizes[len(r[4])] = sizes.get(len(r[4]), 0) + len(r[4])
-print(f"L={L} LS={LS} p={p} F={F} FO2={FO2} W={W} groups={len(keyed)} tiles by group size={sorted(sizes.items())}")
-print(f"read requests {tot_req / rows:6.1f} B/row   L2 misses {tot_miss / rows:6.1f} B/row (+{ES} write)   hit {1 - tot_miss / tot_req:.3f}")
+print(f"L={L} p={p} tiles {len(all_tiles)}")
+for FO in (6, 8):
+    for g, Wg in ((0, 192), (0, 160), (1, 96), (2, 64), (2, 48), (3, 32), (3, 24)):
+        run(group_queues(all_tiles, FO, g), Wg, f"orbit{FO} group 2^{g} W={Wg}")
