@@ -946,6 +946,59 @@ int sd_upload_model(sd_model *m, std::string &err) {
     }
     if ((rc = up(m, m->single_prefix, &d.single_prefix, err))) return rc;
     if ((rc = up(m, m->single_base, &d.single_base, err))) return rc;
+    // General-bond plan (sd_gbond): every hop beyond the leading chain bonds classified by where its sites lie, partner rows of
+    // the suffix-suffix and the mixed bonds tabulated once -- so that second neighbours and long-range lists run as streams and LDS
+    // reads like the chain bonds do, instead of a rank look-up and a gather per row and bond.  Not for the periodic chain's lone
+    // wrap bond, which keeps its own form (suf_part word 3), nor without the packed tables.  SD_GEN_PLAN=0: the per-row form.
+    m->gen.clear(); m->gen_ss_part.clear(); m->mix_part.clear();
+    d.n_gen = 0; d.n_gen_mixed = 0; d.n_suf_rows = (int)m->suf_states.size();
+    d.gen = nullptr; d.gen_ss_part = nullptr; d.mix_part = nullptr;
+    {
+      const int p = m->p, LS = m->LS, nn = d.nn_hops;
+      const bool wrap_only = d.n_hop == nn + 1 && d.wrap_hop == nn;
+      const char *ge = getenv("SD_GEN_PLAN");
+      if (!m->suf_part.empty() && d.n_hop > nn && !wrap_only && !(ge && atoi(ge) == 0)) {
+        const size_t nsr = m->suf_states.size();
+        int n_ss = 0;
+        std::vector<int> mix_site(LS, 0);
+        for (int h = nn; h < d.n_hop; ++h) {
+          const int bi = m->hop_i[h] - 1, bj = m->hop_j[h] - 1;
+          sd_gbond g{-1, 0u, 0, 0, m->hop_J[h]};
+          if (bi != bj) {
+            const bool ip = bi < p, jp = bj < p;
+            if (ip && jp) { g.kind = 0; g.pmask = (1u << bi) | (1u << bj); }
+            else if (!ip && !jp) { g.kind = 1; g.pmask = (1u << (bi - p)) | (1u << (bj - p)); g.slot = n_ss++; }   // (pmask: the two SUFFIX bits, host use only)
+            else { g.kind = 2; g.pb = ip ? bi : bj; g.pmask = 1u << g.pb; g.slot = (ip ? bj : bi) - p; mix_site[g.slot] = 1; ++d.n_gen_mixed; }
+          }
+          m->gen.push_back(g);
+        }
+        const int n_chunks = (n_ss + 11) / 12;
+        m->gen_ss_part.assign((size_t)std::max(n_chunks, 1) * nsr * 4, 0u);
+        for (const sd_gbond &g : m->gen)
+          if (g.kind == 1) {
+            const int chunk = g.slot / 12, f = g.slot % 12;
+            for (size_t k = 0; k < nsr; ++k) {
+              const uint32_t sg = m->suf_states[k];
+              if (__builtin_popcount(sg & g.pmask) != 1) continue;
+              const uint32_t partner = (uint32_t)m->suf_rank[sg ^ g.pmask] + 1u;              // same sector: same popcount
+              m->gen_ss_part[((size_t)chunk * nsr + k) * 4 + (size_t)(f / 3)] |= partner << (10 * (f % 3));
+            }
+          }
+        m->mix_part.assign((size_t)LS * nsr, 0);
+        for (int sb = 0; sb < LS; ++sb)
+          if (mix_site[sb])
+            for (size_t k = 0; k < nsr; ++k) {
+              const uint32_t sg = m->suf_states[k];
+              m->mix_part[(size_t)sb * nsr + k] = (uint16_t)(((uint32_t)m->suf_rank[sg ^ (1u << sb)] + 1u) | (((sg >> sb) & 1u) << 15));
+            }
+        for (sd_gbond &g : m->gen) if (g.kind == 1) g.pmask = 0u;      // device side: unused
+        if ((rc = up(m, m->gen, &d.gen, err))) return rc;
+        if ((rc = up(m, m->gen_ss_part, &d.gen_ss_part, err))) return rc;
+        if ((rc = up(m, m->mix_part, &d.mix_part, err))) return rc;
+        d.n_gen = (int)m->gen.size();
+        d.wrap_hop = -1;                                   // the wrap bond, if any, is one of the plan's mixed bonds
+      }
+    }
   }
   // General couplings (no exact shortcut for the diagonal): the reference's sequential sum of up to 2L-1 rounded terms per
   // row is evaluated once per model and read back as 8 B/row by every apply -- the same bits, as fast as the hand-tuned
@@ -968,6 +1021,7 @@ int sd_upload_model(sd_model *m, std::string &err) {
   {
     const bool chain_diag = d.diag_mode == 1 && (d.n_zz == 0 || (d.n_zz_nn == m->L - 1 && d.n_zz == d.n_zz_nn));
     d.need_sig = (d.n_hop > d.nn_hops) || !(d.diag_cache || chain_diag) || !d.suf_part;
+    d.need_sig_gen = !(d.diag_cache || chain_diag);
   }
   m->dev_ready = true;
   return SD_OK;

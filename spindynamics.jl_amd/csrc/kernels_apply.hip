@@ -72,6 +72,9 @@ namespace {
 #ifndef SD_LB_F64
 #define SD_LB_F64 5
 #endif
+#ifndef SD_LB_GEN
+#define SD_LB_GEN 4         // the form with the general-bond plan (GEN)
+#endif
 #ifndef SD_FAR_DEPTH
 #define SD_FAR_DEPTH 2      // register sets of the far-bond streams (1: no ping-pong, fewer registers, more waves)
 #endif
@@ -83,8 +86,8 @@ namespace {
 // 16-byte load per row, L2/L1 resident: 64 KB for all sectors): a bond costs a shift, a mask, an LDS read and the
 // multiply-add -- the binomial form (!PK: popcount, LDS binomial look-up, two bit tests, signed offset, select) cost ~14
 // lane-operations per row and bond, half of the kernel's VALU stream (VERDICT r03, weak point 5).
-template <int NC, int R, int BLOCK, bool FMA, bool PK, bool DIAG = false>
-__global__ __launch_bounds__(BLOCK, (NC == 2 ? SD_LB_C128 : SD_LB_F64)) void k_apply_tiled(sd_dev_model dm, double *__restrict__ out_,
+template <int NC, int R, int BLOCK, bool FMA, bool PK, bool DIAG = false, bool GEN = false>
+__global__ __launch_bounds__(BLOCK, (GEN ? SD_LB_GEN : NC == 2 ? SD_LB_C128 : SD_LB_F64)) void k_apply_tiled(sd_dev_model dm, double *__restrict__ out_,
                                                        const double *__restrict__ psi_, int epi, sd_epi_args ea,
                                                        double *__restrict__ partials, int max_len) {
   using V = typename VT<NC>::type;
@@ -118,7 +121,10 @@ __global__ __launch_bounds__(BLOCK, (NC == 2 ? SD_LB_C128 : SD_LB_F64)) void k_a
   const int len = rec.len;
   const int nU = rec.nU;                            // rows whose first suffix site is up
   const int nn = dm.nn_hops;
-  const bool need_sig = !PK || dm.need_sig;
+  // GEN: the model's general bonds run from the host-resolved plan dm.gen (section 4b); the suffix configurations are then needed
+  // for the diagonal at most
+  static_assert(!GEN || (PK && !DIAG), "general-bond plan: packed tables only");
+  const bool need_sig = GEN ? (dm.need_sig_gen != 0) : (!PK || dm.need_sig);
   unsigned long long *stamp = (DIAG && dm.stamps) ? dm.stamps + 8 * (size_t)tix : nullptr;
 #define SD_STAMP(k)                                                                   \
   do {                                                                                \
@@ -310,7 +316,7 @@ __global__ __launch_bounds__(BLOCK, (NC == 2 ? SD_LB_C128 : SD_LB_F64)) void k_a
   // address unit pays per line (+19 % on the apply).  The partner tile is streamed instead, coalesced like a far bond, into a
   // second LDS image (the stream registers are free now) and read there after the suffix bonds, at the row the packed table names.
   // (not for the 8-row Float64 form: its 96 registers -- five waves -- have no room, the code would spill; it keeps the gather)
-  const bool wrap = PK && !(NC == 1 && R == 8) && nn > 0 && dm.wrap_hop == nn;
+  const bool wrap = !GEN && PK && !(NC == 1 && R == 8) && nn > 0 && dm.wrap_hop == nn;
   bool wrap_on = false;
   if (wrap) {
     const uint32_t Q = P ^ (1u << dm.wrap_pb);
@@ -372,7 +378,7 @@ __global__ __launch_bounds__(BLOCK, (NC == 2 ? SD_LB_C128 : SD_LB_F64)) void k_a
   };
   // the first general bond's values are requested now, into the idle stream registers, so that their latency hides behind
   // the suffix phase; they are accumulated in their turn, after the suffix bonds
-  const bool have_g = nn < dm.n_hop;
+  const bool have_g = !GEN && nn < dm.n_hop;
   double gJ = 0.0;
   GBond g0{0, 0u, 0, -1};
   auto request_g0 = [&]() {
@@ -429,7 +435,111 @@ __global__ __launch_bounds__(BLOCK, (NC == 2 ? SD_LB_C128 : SD_LB_F64)) void k_a
       }
     }
   }
-  // ---- the general bonds in list order ----
+  // ---- 4b. the general bonds in list order, from the plan (sd_gbond) ----
+  // prefix-prefix bonds: whole-tile streams, two register sets in flight (the next flippable one is requested before the current is
+  // accumulated -- requesting early does not change the order of the sums); suffix-suffix bonds: LDS reads at the row the packed
+  // table gen_ss_part names (one 16-byte load per row and 12 bonds); mixed bonds: the ONE partner tile streamed into the second
+  // LDS image and read at the row mix_part names.  Rows without the hop add J * 0.
+  if constexpr (GEN) {
+    constexpr uint32_t SH = NC == 2 ? 4 : 3;            // log2(sizeof(V))
+    const unsigned char *tb = reinterpret_cast<const unsigned char *>(tile);
+    const unsigned char *tb2 = reinterpret_cast<const unsigned char *>(tile2);
+    u4 pt2[R];
+    int cur_chunk = -1;
+    auto gissue = [&](int64_t gbase, V(&v)[R]) {
+      const V *__restrict__ pbp = (halo && gbase >= dm.n_local) ? halo + (gbase - dm.n_local) : psi + gbase;
+      const __amdgpu_buffer_rsrc_t rs = make_rsrc(pbp, (uint32_t)len * ES);      // same prefix filling: same length, same row offsets
+#pragma unroll
+      for (int r = 0; r < R; ++r) buf_load(v[r], rs, off0 + (uint32_t)(r * 64) * ES);
+    };
+    for (int hb = 0; hb < dm.n_gen; hb += 64) {
+      const int nb = dm.n_gen - hb < 64 ? dm.n_gen - hb : 64;
+      // lane k <-> bond hb + k: the partner bases of the flippable prefix-prefix bonds of this block, one gather per wave
+      // (the descriptors stay in the lanes and are read with v_readlane per bond: a scalar load per bond would put a memory
+      // latency at the head of every one of them)
+      int64_t base_k = -1;
+      sd_gbond gl{-1, 0u, 0, 0, 0.0};
+      if (lane < nb) {
+        gl = dm.gen[hb + lane];
+        if (gl.kind == 0 && __popc(P & gl.pmask) == 1) base_k = dm.addr[P ^ gl.pmask];
+      }
+      uint64_t todo = __ballot(base_k >= 0);
+      int in_a = -1, in_b = -1;                            // the bonds whose rows are in flight in va / vb (consumed in this order)
+      if (todo) { in_a = next_lane(todo); gissue(rl64(base_k, in_a), va); }
+      if (todo) { in_b = next_lane(todo); gissue(rl64(base_k, in_b), vb); }
+      for (int k = 0; k < nb; ++k) {
+        sd_gbond gb;                                      // wave-uniform
+        gb.kind = rl(gl.kind, k); gb.pmask = (uint32_t)rl((int)gl.pmask, k); gb.slot = rl(gl.slot, k); gb.pb = rl(gl.pb, k);
+        gb.J = rld(gl.J, k);
+        if (gb.kind == 0) {
+          if (k == in_a) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[r] = accum<false>(acc[r], gb.J, va[r]);
+            in_a = -1;
+            if (todo) { in_a = next_lane(todo); gissue(rl64(base_k, in_a), va); }
+          } else if (k == in_b) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[r] = accum<false>(acc[r], gb.J, vb[r]);
+            in_b = -1;
+            if (todo) { in_b = next_lane(todo); gissue(rl64(base_k, in_b), vb); }
+          }
+        } else if (gb.kind == 1) {
+          const int chunk = gb.slot / 12, f = gb.slot - 12 * chunk;
+          if (chunk != cur_chunk) {
+            cur_chunk = chunk;
+            const __amdgpu_buffer_rsrc_t rp2 = make_rsrc(dm.gen_ss_part + 4 * ((size_t)chunk * (size_t)dm.n_suf_rows + (size_t)rec.suf_off), (uint32_t)len * 16u);
+#pragma unroll
+            for (int r = 0; r < R; ++r) pt2[r] = __builtin_amdgcn_raw_buffer_load_b128(rp2, (uint32_t)i0 * 16u + (uint32_t)(r * 64) * 16u, 0, 0);
+          }
+          const int w = f / 3, sh = 10 * (f - 3 * w);
+          V v[R];
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const u4 q = pt2[r];
+            const uint32_t word = w == 0 ? q.x : w == 1 ? q.y : w == 2 ? q.z : q.w;
+            v[r] = *reinterpret_cast<const V *>(tb + ((((word >> sh) & 0x3FFu)) << SH));
+          }
+#pragma unroll
+          for (int r = 0; r < R; ++r) acc[r] = accum<false>(acc[r], gb.J, v[r]);
+        } else if (gb.kind == 2) {
+          const uint32_t Q = P ^ gb.pmask;
+          const int t2q = dm.nup - __popc(Q);
+          const bool ok = t2q >= 0 && t2q <= LS;
+          __syncthreads();                                 // the previous mixed bond's readers of the second image are done
+          if (ok) {
+            const int64_t qb = dm.addr[Q];
+            const int lenq = (int)dm.binom[LS * (SD_MAX_L + 1) + t2q];
+            const V *__restrict__ pbq = (halo && qb >= dm.n_local) ? halo + (qb - dm.n_local) : psi + qb;
+            const __amdgpu_buffer_rsrc_t rq = make_rsrc(pbq, (uint32_t)lenq * ES);
+            for (int c0 = 0; c0 < lenq; c0 += BLOCK * R) {   // (the partner tile's sector is t' +- 1: it may be longer than BLOCK * R rows)
+              V tmp[R];
+#pragma unroll
+              for (int r = 0; r < R; ++r) buf_load(tmp[r], rq, off0 + (uint32_t)(c0 + r * 64) * ES);
+#pragma unroll
+              for (int r = 0; r < R; ++r)
+                if (c0 + i0 + r * 64 < lenq) tile2[1 + c0 + i0 + r * 64] = tmp[r];
+            }
+            if (tid == 0) tile2[0] = V{};
+          }
+          __syncthreads();
+          if (ok) {
+            const __amdgpu_buffer_rsrc_t rm = make_rsrc(dm.mix_part + ((size_t)gb.slot * (size_t)dm.n_suf_rows + (size_t)rec.suf_off), (uint32_t)len * 2u);
+            const uint32_t bpb = (P >> gb.pb) & 1u;
+            uint32_t w16[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) w16[r] = buf_load_u16(rm, (uint32_t)i0 * 2u + (uint32_t)(r * 64) * 2u);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+              const bool has = (w16[r] >> 15) != bpb;       // the row's suffix site differs from the tile's prefix site
+              const uint32_t ad = has ? ((w16[r] & 0x3FFu) << SH) : 0u;
+              acc[r] = accum<false>(acc[r], gb.J, *reinterpret_cast<const V *>(tb2 + ad));
+            }
+          }
+        }
+      }
+    }
+  }
+  // ---- the general bonds in list order (without a plan) ----
   if (wrap) {
     __syncthreads();                                     // the second image is complete (every wave takes this branch or none)
     if (wrap_on) {
@@ -765,13 +875,13 @@ int sd_launch_epilogue_only(sd_ctx *ctx, int dtype, int64_t n, void *out, const 
 }
 namespace {
 
-template <int NC, int R, int BLOCK, bool FMA, bool PK>
+template <int NC, int R, int BLOCK, bool FMA, bool PK, bool GEN = false>
 int launch_tiled_cfg(sd_ctx *ctx, const sd_dev_model &dm, int nt, size_t shmem, double *out, const double *psi, int epi,
                      const sd_epi_args &ea, int max_len) {
   // the stamped (DIAG) instantiation exists for one configuration only and is reached through sd_debug_phase_profile
-  void (*kern)(sd_dev_model, double *, const double *, int, sd_epi_args, double *, int) = k_apply_tiled<NC, R, BLOCK, FMA, PK>;
+  void (*kern)(sd_dev_model, double *, const double *, int, sd_epi_args, double *, int) = k_apply_tiled<NC, R, BLOCK, FMA, PK, false, GEN>;
   // ... and for the SD_DEBUG_SKIP timing ablations: the production instantiations carry no run-time debug branches
-  if constexpr (NC == 2 && FMA && PK && (BLOCK == 256 || BLOCK == 128 || BLOCK == 64))
+  if constexpr (NC == 2 && FMA && PK && !GEN && (BLOCK == 256 || BLOCK == 128 || BLOCK == 64))
     if (dm.stamps || dm.dbg) kern = k_apply_tiled<NC, R, BLOCK, FMA, PK, true>;
   // per kernel AND per device, so no cache: cheap next to a launch, and only the SD_SUFFIX_BITS >= 13 tiles get here
   if (shmem > 48 * 1024)
@@ -796,6 +906,13 @@ int launch_tiled(sd_ctx *ctx, const sd_dev_model &dm, int nt, int cls, size_t sh
     }
     return sd_set_err(ctx, SD_EINTERNAL, "bad tile length class for a plan without the packed partner table");
   }
+  if (dm.n_gen > 0)     // general bonds from the host-resolved plan (4 rows per thread for both element types)
+    switch (cls) {
+      case 0: return launch_tiled_cfg<NC, R, 64, FMA, true, true>(ctx, dm, nt, shmem, out, psi, epi, ea, max_len);
+      case 1: return launch_tiled_cfg<NC, R, 128, FMA, true, true>(ctx, dm, nt, shmem, out, psi, epi, ea, max_len);
+      case 2: return launch_tiled_cfg<NC, R, 256, FMA, true, true>(ctx, dm, nt, shmem, out, psi, epi, ea, max_len);
+      default: return sd_set_err(ctx, SD_EINTERNAL, "bad tile length class");
+    }
   if constexpr (NC == 1) {
     // Float64: 8 rows per thread in workgroups of half the size (same registers as 4 ComplexF64 rows; the per-thread
     // set-up -- far-bond list, descriptors -- is paid once per 8 rows).  SD_F64_ROWS=4 keeps 4 rows per thread.
@@ -854,7 +971,7 @@ int sd_launch_apply(sd_ctx *ctx, const sd_model *m, int dtype, void *out, const 
         const int cls = m->seg_cls[sg];
         const int seg_max = std::min(max_len, (64 << cls) * 4);
         size_t shmem = (size_t)(seg_max + 1) * esz + 16 * SD_BIN_STRIDE * sizeof(int) + 32 * sizeof(double) + 16;
-        if (dm.wrap_hop >= 0 && dm.wrap_hop == dm.nn_hops) shmem += (size_t)(m->max_tile_len_all + 1) * esz;   // the wrap bond's partner tile: any length class, owned or imported
+        if ((dm.wrap_hop >= 0 && dm.wrap_hop == dm.nn_hops) || dm.n_gen_mixed > 0) shmem += (size_t)(m->max_tile_len_all + 1) * esz;   // the wrap bond's partner tile: any length class, owned or imported
         // (the 8-row Float64 form does not use it: launch_tiled; asking for it there would only cost occupancy -- but it is 7.4 KB)
         {   // experiment knob: SD_LDS_MIN_KB_<cls> raises the LDS request of a class, i.e. lowers its workgroups per CU
           static int min_kb[SD_N_LEN_CLASS] = {-1, -1, -1, -1, -1};

@@ -42,6 +42,21 @@ struct sd_tile_rec {
   int32_t pad0, pad1;
 };
 
+// A hop of the list beyond the leading chain bonds (the periodic chain's wrap, second neighbours, long-range lists:
+// src/SpinModel.jl:44-46, 74-78), classified on the host by where its two sites lie (basis.cpp, build_general_plan):
+//   kind 0, both in the prefix : tile P maps onto tile P ^ pmask at the same row offset -- a coalesced stream, like a chain bond;
+//   kind 1, both in the suffix : the partner row is in this tile, its row + 1 is field `slot` of the packed table gen_ss_part;
+//   kind 2, one in each        : every partner row lies in the ONE tile P ^ pmask (pmask = the prefix site), at the row mix_part
+//                                names for suffix site `slot`; the kernel streams that tile into a second LDS image;
+//   kind -1                    : i == j, never flips (the reference accepts such a bond and it does nothing).
+struct sd_gbond {
+  int32_t kind;
+  uint32_t pmask;
+  int32_t slot;
+  int32_t pb;        // kind 2: the prefix site (0-based bit of P)
+  double J;
+};
+
 struct sd_xfer_team;   // host threads of the staged host <-> device transfers (xfer.cpp)
 
 struct sd_ctx {
@@ -134,6 +149,17 @@ struct sd_dev_model {
   const int64_t *single_base;
   const sd_tile_rec *single_rec;
   unsigned long long *stamps;    // diagnostic builds only (sd_debug_phase_profile): 8 s_memtime stamps per tile, else null
+  // General bonds of a tiled plan with the packed tables (LS <= 12), resolved on the host: n_gen = n_hop - nn_hops entries in list
+  // order, or 0 (no plan: k_apply_tiled then looks every general partner up per row).  gen_ss_part: per chunk of 12 suffix-suffix
+  // bonds one 16-byte entry per row of every suffix sector (chunk-major), 10-bit fields like suf_part.  mix_part: per suffix
+  // site s one uint16 per row of every suffix sector -- bits 0..9 = 1 + rank of (sigma ^ bit s) inside ITS sector, bit 15 = bit s
+  // of sigma.  n_suf_rows = rows of all suffix sectors together (2^LS).
+  int n_gen, n_gen_mixed;
+  int n_suf_rows;
+  int need_sig_gen;              // the GEN form of the kernel needs the suffix configurations only for a diagonal without shortcut or cache
+  const sd_gbond *gen;
+  const uint32_t *gen_ss_part;
+  const uint16_t *mix_part;
 };
 
 #define SD_N_LEN_CLASS 5   // tile length classes: workgroups of 64, 128, 256, 512, 1024 threads (x 4 rows)
@@ -161,6 +187,9 @@ struct sd_model {
   std::vector<uint32_t> suf_part;   // packed suffix-bond partner table (see sd_dev_model), empty for LS > 12
   std::vector<uint8_t> suf_dg;
   int wrap_hop = -1, wrap_pb = 0;   // see sd_dev_model
+  std::vector<sd_gbond> gen;        // general-bond plan (see sd_dev_model), empty: none
+  std::vector<uint32_t> gen_ss_part;
+  std::vector<uint16_t> mix_part;
   std::vector<int64_t> far_base;
   std::vector<int32_t> suf_off;
   std::vector<sd_slab> recv_slabs, send_slabs;

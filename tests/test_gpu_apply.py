@@ -214,3 +214,46 @@ def test_diagonal_cache_on_off_bit_exact(pkg, O, cache, monkeypatch):
         out = np.empty_like(psi)
         pkg.apply_rescaled_H(out, psi, pkg.apply_H, m, a, b)
         assert np.array_equal(out, O.apply_rescaled_H(r, psi, a, b))
+
+
+def _bond_lists(L, kind):
+    """hopping / zz lists of build_model (src/SpinModel.jl:23-46) beyond the chain"""
+    hop, zz = [], []
+    if kind == "all-pairs":            # long_range_hopping: every pair, J(i, j) = 1 / (j - i)^2, in the reference's order
+        for i in range(1, L + 1):
+            for j in range(i + 1, L + 1):
+                hop.append((i, j, 0.5 / (j - i) ** 2)); zz.append((i, j, 1.0 / (j - i) ** 2))
+        return hop, zz
+    ranges = {"j1j2": ((1, 1.0), (2, 0.5)), "j1j2j3": ((1, 1.0), (2, 0.5), (3, -0.3)), "j1j2-periodic": ((1, 1.0), (2, 0.37))}[kind]
+    for d, J in ranges:
+        for i in range(1, L + 1):
+            j = i + d
+            if j > L:
+                if "periodic" not in kind:
+                    continue
+                j -= L
+            hop.append((i, j, 0.5 * J)); zz.append((i, j, J))
+    return hop, zz
+
+
+@pytest.mark.parametrize("L,nup,kind,ls", [(16, 8, "j1j2", 12), (20, 10, "j1j2", 12), (20, 9, "j1j2j3", 10), (19, 9, "j1j2-periodic", 12),
+                                            (18, 9, "all-pairs", 12),      # 153 bonds: three blocks of 64, 55 suffix-suffix bonds in 5 table chunks
+                                            (20, 10, "all-pairs", 8), (14, 7, "all-pairs", 12), (22, 11, "j1j2-periodic", 12)])
+def test_models_with_longer_bonds_bit_exact_vs_oracle(pkg, O, L, nup, kind, ls, monkeypatch):
+    """Second / third neighbours and all-pairs lists through the general-bond plan of k_apply_tiled (prefix-prefix streams,
+    suffix-suffix partners from the packed table, mixed bonds through the second LDS image): bit-exact against the oracle, and equal
+    to the per-row form the plan replaces (SD_GEN_PLAN=0)."""
+    monkeypatch.setenv("SD_SUFFIX_BITS", str(ls))
+    hop, zz = _bond_lists(L, kind)
+    m = pkg.build_model(L, nup=nup, hopping=hop, zz=zz)
+    r = O.build_model(L, nup=nup, hopping=hop, zz=zz)
+    monkeypatch.setenv("SD_GEN_PLAN", "0")
+    m0 = pkg.build_model(L, nup=nup, hopping=hop, zz=zz)
+    for cplx in (True, False):
+        psi = rand_vec(m.N, 7 + L, cplx)
+        out, out0 = np.empty_like(psi), np.empty_like(psi)
+        pkg.apply_H(out, psi, m)
+        pkg.apply_H(out0, psi, m0)
+        want = O.apply_H(r, psi)
+        assert np.array_equal(out, want), f"max diff {np.abs(out - want).max()}"
+        assert np.array_equal(out0, want)

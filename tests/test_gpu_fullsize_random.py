@@ -65,8 +65,39 @@ CASES = [
     (28, 14, {"boundary": "periodic"}, "c128", 12000),                               # the wrap bond (L, 1)
     (28, 12, {"Jz": 0.37, "boundary": "periodic"}, "f64", 12000),
     (34, 17, {}, "f64", 12000),                                                      # rows past 2^31
+    (28, 14, {"ranges": ((1, 1.0), (2, 0.5))}, "c128", 12000),                       # J1-J2: the general-bond plan (streams, packed table, second LDS image)
+    (28, 13, {"ranges": ((1, 1.0), (2, 0.5), (3, -0.3)), "boundary": "periodic"}, "f64", 12000),
+    (26, 13, {"ranges": tuple((d, 1.0 / d ** 2) for d in range(1, 26))}, "c128", 6000),   # every pair, 1/r^2: 325 bonds
     (36, 18, {}, "f64", 8000),                                                       # config 5's sector whole on one GPU: N = 9.08e9 rows, past 2^32
 ]
+
+
+def bond_lists(L, kw):
+    """(hopping, zz, field) of the model: XXZChain's lists (src/SpinModel.jl:63-90) or, with kw["ranges"], a build_model with bonds
+    (i, i + d) of strength J for every (d, J) of the ranges, distance by distance (periodic: wrapped)"""
+    hop, zz = [], []
+    if "ranges" in kw:
+        for d, J in kw["ranges"]:
+            for i in range(1, L + 1):
+                j = i + d
+                if j > L:
+                    if kw.get("boundary") != "periodic":
+                        continue
+                    j -= L
+                hop.append((i, j, 0.5 * J)); zz.append((i, j, J))
+        return hop, zz, [0.0] * L
+    Jxy, Jz, hz = kw.get("Jxy", 1.0), kw.get("Jz", 1.0), kw.get("hz", 0.0)
+    bonds = [(i, i + 1) for i in range(1, L)]
+    if kw.get("boundary") == "periodic" and L > 2:
+        bonds.append((L, 1))                                                           # src/SpinModel.jl:74-78
+    return [(i, j, Jxy / 2) for (i, j) in bonds], [(i, j, Jz) for (i, j) in bonds], [hz] * L      # src/SpinModel.jl:71
+
+
+def make_model(pkg, L, nup, kw):
+    if "ranges" in kw:
+        hop, zz, _f = bond_lists(L, kw)
+        return pkg.build_model(L, nup=nup, hopping=hop, zz=zz)
+    return pkg.XXZChain(L, nup=nup, **kw)
 
 
 def reference_rows(psi, rows, L, nup, kw, dtype):
@@ -75,17 +106,13 @@ def reference_rows(psi, rows, L, nup, kw, dtype):
     import torch
     s = unrank(rows, L, nup)
     assert (rank(s, L, nup) == rows).all()                                             # the two restatements agree with each other
-    Jxy, Jz, hz = kw.get("Jxy", 1.0), kw.get("Jz", 1.0), kw.get("hz", 0.0)
-    bonds = [(i, i + 1) for i in range(1, L)]
-    if kw.get("boundary") == "periodic" and L > 2:
-        bonds.append((L, 1))                                                           # src/SpinModel.jl:74-78
-    hop = Jxy / 2                                                                      # src/SpinModel.jl:71
+    hops, zzs, field = bond_lists(L, kw)
     sz = lambda site: np.where((s >> np.uint64(site - 1)) & np.uint64(1), 0.5, -0.5)   # noqa: E731
 
     d = np.zeros(len(rows))
     for i in range(1, L + 1):                                                          # src/Hamiltonian.jl:228-233
-        d = d + hz * sz(i)
-    for (i, j) in bonds:                                                               # :235-241
+        d = d + field[i - 1] * sz(i)
+    for (i, j, Jz) in zzs:                                                             # :235-241
         d = d + (Jz * sz(i)) * sz(j)
 
     def gather(idx):
@@ -95,7 +122,7 @@ def reference_rows(psi, rows, L, nup, kw, dtype):
     own_re, own_im = gather(rows)
     val_re = d * own_re                                                                # :243
     val_im = d * own_im if own_im is not None else None
-    for (i, j) in bonds:                                                               # :248-267
+    for (i, j, hop) in hops:                                                           # :248-267
         bi = (s >> np.uint64(i - 1)) & np.uint64(1)
         bj = (s >> np.uint64(j - 1)) & np.uint64(1)
         fl = bi != bj
@@ -121,7 +148,7 @@ def random_vector(pkg, model, N, dtype, seed):
 @pytest.mark.parametrize("L,nup,kw,dtype,n_random", CASES)
 def test_random_vector_sampled_rows_bit_exact_full_size(pkg, L, nup, kw, dtype, n_random):
     import torch
-    model = pkg.XXZChain(L, nup=nup, **kw)
+    model = make_model(pkg, L, nup, kw)
     N = model.N
     esz = 16 if dtype == "c128" else 8
     free, _ = torch.cuda.mem_get_info()

@@ -47,16 +47,44 @@ def test_virtual_shards_full_basis_by_top_bits(pkg, L, P, kw):
     check_virtual_shards(pkg, L, None, P, "range", kw, need_interior=False)
 
 
-def check_virtual_shards(pkg, L, nup, P, mode, kw, need_interior=True):
+def j1j2_model(pkg, L, nup, J2=0.5, J3=0.0, periodic=False):
+    """build_model (src/SpinModel.jl:23-38) with second (and third) neighbour bonds behind the chain bonds"""
+    hop, zz = [], []
+    for d, J in ((1, 1.0), (2, J2), (3, J3)):
+        if J == 0.0:
+            continue
+        for i in range(1, L + 1):
+            j = i + d
+            if j > L:
+                if not periodic:
+                    continue
+                j -= L
+            hop.append((i, j, 0.5 * J)); zz.append((i, j, J))
+    return pkg.build_model(L, nup=nup, hopping=hop, zz=zz)
+
+
+@pytest.mark.parametrize("mode", ["range", "class"])
+@pytest.mark.parametrize("L,nup,P,ls,J3,periodic", [(18, 9, 2, 9, 0.0, False), (20, 10, 4, 10, 0.25, False), (20, 9, 8, 8, 0.0, True),
+                                                   (22, 11, 3, 12, 0.3, True)])
+def test_virtual_shards_with_second_neighbour_bonds_bit_identical(pkg, L, nup, P, ls, J3, periodic, mode, monkeypatch):
+    """The general-bond plan of a sharded model (k_apply_tiled GEN): prefix-prefix partner tiles and the partner tile of a mixed bond may
+    live on another rank, i.e. in the halo."""
+    monkeypatch.setenv("SD_SUFFIX_BITS", str(ls))
+    check_virtual_shards(pkg, L, nup, P, mode, {}, need_interior=False, make=lambda: j1j2_model(pkg, L, nup, 0.5, J3, periodic))
+
+
+def check_virtual_shards(pkg, L, nup, P, mode, kw, need_interior=True, make=None):
     import torch
-    full = pkg.XXZChain(L, nup=nup, **kw)
+    if make is None:
+        make = lambda: pkg.XXZChain(L, nup=nup, **kw)       # noqa: E731
+    full = make()
     rng = np.random.default_rng(L * P)
     psi = rng.standard_normal(full.N) + 1j * rng.standard_normal(full.N)
     want = np.empty_like(psi)
     pkg.apply_H(want, psi, full)
     ops, bufs = [], []
     for r in range(P):
-        m = pkg.XXZChain(L, nup=nup, **kw)
+        m = make()
         op = pkg.ShardedOperator(m, r, P, mode=mode)
         buf = torch.from_numpy(psi[m.local_rows()].copy()).cuda()
         op.halo(buf).fill_(float("nan"))
