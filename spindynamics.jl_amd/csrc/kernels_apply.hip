@@ -73,7 +73,10 @@ namespace {
 #define SD_LB_F64 5
 #endif
 #ifndef SD_LB_GEN
-#define SD_LB_GEN 4         // the form with the general-bond plan (GEN)
+#define SD_LB_GEN 5         // the form with the general-bond plan (GEN)
+#endif
+#ifndef SD_GEN_DEPTH
+#define SD_GEN_DEPTH 1      // register sets of its prefix-prefix streams
 #endif
 #ifndef SD_FAR_DEPTH
 #define SD_FAR_DEPTH 2      // register sets of the far-bond streams (1: no ping-pong, fewer registers, more waves)
@@ -436,16 +439,17 @@ __global__ __launch_bounds__(BLOCK, (GEN ? SD_LB_GEN : NC == 2 ? SD_LB_C128 : SD
     }
   }
   // ---- 4b. the general bonds in list order, from the plan (sd_gbond) ----
-  // prefix-prefix bonds: whole-tile streams, two register sets in flight (the next flippable one is requested before the current is
-  // accumulated -- requesting early does not change the order of the sums); suffix-suffix bonds: LDS reads at the row the packed
-  // table gen_ss_part names (one 16-byte load per row and 12 bonds); mixed bonds: the ONE partner tile streamed into the second
-  // LDS image and read at the row mix_part names.  Rows without the hop add J * 0.
+  // prefix-prefix bonds: whole-tile streams; the next flippable one is requested as soon as the current one has been accumulated,
+  // whatever lies between them in the list -- requesting early does not change the order of the sums.  (One register set: with two
+  // in flight the form needs 113 registers, four waves, and is 6-10 % slower: profiles/ablation_r04.md section 10.)  Suffix-suffix
+  // bonds: LDS reads at the row the packed table gen_ss_part names (one 4-byte load per row and three bonds); mixed bonds: the
+  // ONE partner tile streamed into the second LDS image and read at the row mix_part names.  Rows without the hop add J * 0.
   if constexpr (GEN) {
     constexpr uint32_t SH = NC == 2 ? 4 : 3;            // log2(sizeof(V))
     const unsigned char *tb = reinterpret_cast<const unsigned char *>(tile);
     const unsigned char *tb2 = reinterpret_cast<const unsigned char *>(tile2);
-    u4 pt2[R];
-    int cur_chunk = -1;
+    uint32_t ptw[R];                                     // the current word of the packed table: three suffix-suffix bonds
+    int cur_word = -1;
     auto gissue = [&](int64_t gbase, V(&v)[R]) {
       const V *__restrict__ pbp = (halo && gbase >= dm.n_local) ? halo + (gbase - dm.n_local) : psi + gbase;
       const __amdgpu_buffer_rsrc_t rs = make_rsrc(pbp, (uint32_t)len * ES);      // same prefix filling: same length, same row offsets
@@ -464,9 +468,15 @@ __global__ __launch_bounds__(BLOCK, (GEN ? SD_LB_GEN : NC == 2 ? SD_LB_C128 : SD
         if (gl.kind == 0 && __popc(P & gl.pmask) == 1) base_k = dm.addr[P ^ gl.pmask];
       }
       uint64_t todo = __ballot(base_k >= 0);
-      int in_a = -1, in_b = -1;                            // the bonds whose rows are in flight in va / vb (consumed in this order)
+      int in_a = -1;                                       // the bond whose rows are in flight in va
+#if SD_GEN_DEPTH == 2
+      int in_b = -1;                                       // ... and in vb (consumed in this order)
+#endif
       if (todo) { in_a = next_lane(todo); gissue(rl64(base_k, in_a), va); }
+#if SD_GEN_DEPTH == 2
       if (todo) { in_b = next_lane(todo); gissue(rl64(base_k, in_b), vb); }
+#endif
+#pragma nounroll
       for (int k = 0; k < nb; ++k) {
         sd_gbond gb;                                      // wave-uniform
         gb.kind = rl(gl.kind, k); gb.pmask = (uint32_t)rl((int)gl.pmask, k); gb.slot = rl(gl.slot, k); gb.pb = rl(gl.pb, k);
@@ -477,28 +487,30 @@ __global__ __launch_bounds__(BLOCK, (GEN ? SD_LB_GEN : NC == 2 ? SD_LB_C128 : SD
             for (int r = 0; r < R; ++r) acc[r] = accum<false>(acc[r], gb.J, va[r]);
             in_a = -1;
             if (todo) { in_a = next_lane(todo); gissue(rl64(base_k, in_a), va); }
-          } else if (k == in_b) {
+          }
+#if SD_GEN_DEPTH == 2
+          else if (k == in_b) {
 #pragma unroll
             for (int r = 0; r < R; ++r) acc[r] = accum<false>(acc[r], gb.J, vb[r]);
             in_b = -1;
             if (todo) { in_b = next_lane(todo); gissue(rl64(base_k, in_b), vb); }
           }
+#endif
         } else if (gb.kind == 1) {
-          const int chunk = gb.slot / 12, f = gb.slot - 12 * chunk;
-          if (chunk != cur_chunk) {
-            cur_chunk = chunk;
+          // (one 4-byte word = three bonds per load: a whole 16-byte entry per row, as the chain bonds keep, would hold 16
+          // registers across the streams and cost this form a wave per SIMD)
+          const int wi = gb.slot / 3, sh = 10 * (gb.slot - 3 * wi);
+          if (wi != cur_word) {
+            cur_word = wi;
+            const int chunk = wi >> 2;
             const __amdgpu_buffer_rsrc_t rp2 = make_rsrc(dm.gen_ss_part + 4 * ((size_t)chunk * (size_t)dm.n_suf_rows + (size_t)rec.suf_off), (uint32_t)len * 16u);
+            const uint32_t wo = (uint32_t)(wi & 3) * 4u;
 #pragma unroll
-            for (int r = 0; r < R; ++r) pt2[r] = __builtin_amdgcn_raw_buffer_load_b128(rp2, (uint32_t)i0 * 16u + (uint32_t)(r * 64) * 16u, 0, 0);
+            for (int r = 0; r < R; ++r) ptw[r] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rp2, (uint32_t)i0 * 16u + (uint32_t)(r * 64) * 16u + wo, 0, 0);
           }
-          const int w = f / 3, sh = 10 * (f - 3 * w);
           V v[R];
 #pragma unroll
-          for (int r = 0; r < R; ++r) {
-            const u4 q = pt2[r];
-            const uint32_t word = w == 0 ? q.x : w == 1 ? q.y : w == 2 ? q.z : q.w;
-            v[r] = *reinterpret_cast<const V *>(tb + ((((word >> sh) & 0x3FFu)) << SH));
-          }
+          for (int r = 0; r < R; ++r) v[r] = *reinterpret_cast<const V *>(tb + ((((ptw[r] >> sh) & 0x3FFu)) << SH));
 #pragma unroll
           for (int r = 0; r < R; ++r) acc[r] = accum<false>(acc[r], gb.J, v[r]);
         } else if (gb.kind == 2) {
