@@ -649,3 +649,40 @@ def test_time_evolve_chebyshev_estimates_its_bounds_once_per_model(pkg):
     bounds = pkg.estimate_energy_bounds(pkg.apply_H, m, seed=0)
     c = pkg.time_evolve(m, psi0, 0.2, method="chebyshev", cheb_n=20, Ebounds=bounds)
     assert np.array_equal(a, c)                     # the cached estimate is the one an explicit call gives
+
+
+@pytest.mark.parametrize("L,nup,periodic", [(14, 7, False), (16, 8, True)])
+def test_recursions_on_a_chain_with_second_neighbour_bonds_vs_oracle(pkg, O, L, nup, periodic):
+    """build_model with J1-J2 bonds (the general-bond plan of k_apply_tiled) under every fused store of the recursions: the Lanczos dot,
+    the Chebyshev term, the KPM step with two moments per apply, and the momenta of S(q,w) in one batch."""
+    hop, zz = [], []
+    for d, J in ((1, 1.0), (2, 0.45)):
+        for i in range(1, L + 1):
+            j = i + d
+            if j > L:
+                if not periodic:
+                    continue
+                j -= L
+            hop.append((i, j, 0.5 * J)); zz.append((i, j, J))
+    m = pkg.build_model(L, nup=nup, hopping=hop, zz=zz)
+    r = O.build_model(L, nup=nup, hopping=hop, zz=zz)
+    p0 = cvec(m.N, 1)
+    al, be, nv = pkg.lanczos_tridiag(pkg.apply_H, m, p0, lanc_m=15)
+    al2, be2, nv2 = O.lanczos_tridiag(r, p0, lanc_m=15)
+    assert np.abs(al - al2).max() <= 1e-9 and np.abs(be - be2).max() <= 1e-9 and abs(nv - nv2) <= 1e-12 * nv2
+    x0 = np.random.default_rng(4).standard_normal(m.N)
+    E, gs = pkg.lanczos_groundstate(pkg.apply_H, m, lanc_m=60, psi0=x0)
+    E2, gs2 = O.lanczos_groundstate(r, x0, lanc_m=60)
+    assert abs(E - E2) <= 1e-10
+    psi0 = cvec(m.N, 5)
+    psi0 /= np.linalg.norm(psi0)
+    assert np.abs(pkg.krylov_time_evolve(psi0, 0.4, pkg.apply_H, m, kry_m=30) - O.krylov_time_evolve(r, psi0, 0.4, kry_m=30)).max() <= 1e-11
+    got = pkg.chebyshev_time_evolve(psi0, 0.4, pkg.apply_H, m, cheb_n=80, Ebounds=(-L / 2, L / 2))
+    assert np.abs(got - O.chebyshev_time_evolve(r, psi0, 0.4, cheb_n=80, Ebounds=(-L / 2, L / 2))).max() <= 1e-14
+    a, b = O.rescaling_from_bounds(-L / 2, L / 2)
+    phi = O.Sz_q_vector(r, gs2, np.pi)
+    phi /= np.linalg.norm(phi)
+    assert np.abs(pkg.compute_chebyshev_moments(pkg.apply_H, phi, 120, a, b, m) - O.compute_chebyshev_moments(r, phi, 120, a, b)).max() <= 1e-12
+    q, omega = pkg.momenta(m), np.arange(0.0, 4.0, 0.05)
+    S = pkg.kpm_sqw(gs2, m, q, omega, a=a, b=b, kpm_m=96)
+    assert np.abs(S - O.kpm_sqw(r, gs2, q, omega, a, b, kpm_m=96)).max() <= 1e-8 * max(1.0, np.abs(S).max())
