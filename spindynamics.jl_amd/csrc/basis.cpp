@@ -955,8 +955,8 @@ int sd_upload_model(sd_model *m, std::string &err) {
     d.gen = nullptr; d.gen_ss_part = nullptr; d.mix_part = nullptr;
     {
       const int p = m->p, LS = m->LS, nn = d.nn_hops;
-      const bool wrap_only = d.n_hop == nn + 1 && d.wrap_hop == nn;
       const char *ge = getenv("SD_GEN_PLAN");
+      const bool wrap_only = d.n_hop == nn + 1 && d.wrap_hop == nn && !(ge && atoi(ge) == 2);     // (2: A/B of the plan on the periodic chain)
       if (!m->suf_part.empty() && d.n_hop > nn && !wrap_only && !(ge && atoi(ge) == 0)) {
         const size_t nsr = m->suf_states.size();
         int n_ss = 0;
