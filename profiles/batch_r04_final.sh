@@ -18,5 +18,6 @@ python profiles/smallL_sqw_bench.py > $OUT/smallL_sqw.jsonl 2>&1; cat $OUT/small
 python examples/kpm_sqw.py > $OUT/example_kpm_sqw.txt 2>&1; cat $OUT/example_kpm_sqw.txt
 python profiles/groundstate_bench.py 28 100 > $OUT/groundstate_L28.jsonl 2>&1; cat $OUT/groundstate_L28.jsonl
 python profiles/config_bench.py 2 3 4 > $OUT/configs.jsonl 2>&1; cut -c1-300 $OUT/configs.jsonl
+python profiles/general_bonds_bench.py 28 > $OUT/general_bonds.jsonl 2>&1; python profiles/general_bonds_bench.py 24 2>/dev/null | grep 'all pairs' >> $OUT/general_bonds.jsonl; cut -c1-200 $OUT/general_bonds.jsonl
 
 env SD_BENCH_BACKEND=gloo SD_RELAY=2 SD_RELAY_MIN=0 python bench.py --gpus 4 --L 28 --steps 5 --warmup 2 --no-cpu > $OUT/bench_gloo4.json 2> $OUT/bench_gloo4.err; cut -c1-300 $OUT/bench_gloo4.json; tail -3 $OUT/bench_gloo4.err
