@@ -31,6 +31,10 @@ def test_heisenberg_closed_form_full_size(pkg, L):
     nup = L // 2
     model = pkg.XXZChain(L, nup=nup)
     N = model.N
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()                 # what earlier tests left in torch's caching allocator is not "in use" ...
+    pkg.default_context().release_scratch()  # ... nor are the work vectors the library's context keeps between calls
     free, _ = torch.cuda.mem_get_info()
     if free < 3 * 16 * N + (2 << 30):
         pytest.skip("not enough device memory")
@@ -92,6 +96,10 @@ def test_config5_shard_of_L36_exact(pkg, rank):
         halo.fill_(1.0)
 
     op = pkg.ShardedOperator(model, rank, world, exchange_fn=fill_halo)
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()                 # what earlier tests left in torch's caching allocator is not "in use" ...
+    pkg.default_context().release_scratch()  # ... nor are the work vectors the library's context keeps between calls
     free, _ = torch.cuda.mem_get_info()
     if free < 16 * (2 * op.n_local + op.n_halo) + (4 << 30):
         pytest.skip("not enough device memory")
@@ -199,6 +207,10 @@ def test_config4_chebyshev_L32_full_size(pkg):
     import torch
     L = 32
     model = pkg.XXZChain(L, nup=L // 2)
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()                 # what earlier tests left in torch's caching allocator is not "in use" ...
+    pkg.default_context().release_scratch()  # ... nor are the work vectors the library's context keeps between calls
     free, _ = torch.cuda.mem_get_info()
     if free < 8 * 16 * model.N + (4 << 30):
         pytest.skip("not enough device memory")
@@ -342,6 +354,10 @@ def test_config5_recursions_on_one_rank_full_size(pkg):
     L, world, rank, M = 36, 8, 3, 32
     model = pkg.XXZChain(L, nup=L // 2)
     op = pkg.ShardedOperator(model, rank, world, exchange_fn=lambda o, p, h: None)
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()                 # what earlier tests left in torch's caching allocator is not "in use" ...
+    pkg.default_context().release_scratch()  # ... nor are the work vectors the library's context keeps between calls
     free, _ = torch.cuda.mem_get_info()
     if free < 16 * (5 * op.n_local + op.n_halo + op.n_send) + (6 << 30):
         pytest.skip("not enough device memory")

@@ -151,6 +151,10 @@ def test_random_vector_sampled_rows_bit_exact_full_size(pkg, L, nup, kw, dtype, 
     model = make_model(pkg, L, nup, kw)
     N = model.N
     esz = 16 if dtype == "c128" else 8
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()                 # what earlier tests left in torch's caching allocator is not "in use" ...
+    pkg.default_context().release_scratch()  # ... nor are the work vectors the library's context keeps between calls
     free, _ = torch.cuda.mem_get_info()
     if free < 2 * esz * N + (3 << 30):
         pytest.skip("not enough device memory")
@@ -176,6 +180,10 @@ def test_fused_rescale_and_chebyshev_term_sampled_rows_bit_exact_at_L32(pkg):
     L, nup, kw = 32, 16, {}
     model = pkg.XXZChain(L, nup=nup)
     N = model.N
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()                 # what earlier tests left in torch's caching allocator is not "in use" ...
+    pkg.default_context().release_scratch()  # ... nor are the work vectors the library's context keeps between calls
     free, _ = torch.cuda.mem_get_info()
     if free < 5 * 16 * N + (3 << 30):
         pytest.skip("not enough device memory")
@@ -216,6 +224,10 @@ def test_one_rank_of_the_sharded_L32_apply_on_a_random_vector_equals_the_unshard
     L, nup = 32, 16
     full = pkg.XXZChain(L, nup=nup)
     N = full.N
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()                 # what earlier tests left in torch's caching allocator is not "in use" ...
+    pkg.default_context().release_scratch()  # ... nor are the work vectors the library's context keeps between calls
     free, _ = torch.cuda.mem_get_info()
     if free < 2 * 16 * N + (12 << 30):
         pytest.skip("not enough device memory")
