@@ -3,6 +3,7 @@
 // src/Basis.jl:37-53) from binomial coefficients only: no states[] array and
 // no hash map are ever built for the full dimension.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -370,6 +371,9 @@ int sd_build_plan(sd_model *m, int rank, int nranks, std::string &err) {
   if (m->nup >= 0)
     for (int t = std::max(0, m->nup - (L - LS)); t <= std::min(LS, m->nup); ++t)
       m->max_tile_len_all = std::max<int>(m->max_tile_len_all, (int)std::min<int64_t>(B(m, LS, t), 1 << 30));
+  // (Prefix spaces beyond 2^26 -- dilute sectors of chains with L >= 39 at LS = 12 -- keep the per-row path: the plan's dense prefix
+  // tables cost 13 B x 2^p on the host and its tile order visits all 2^p prefixes; measured with the cap at 28: L=40, nup=10 plans in
+  // 110 s for an apply of ~50 instead of 528 ms, profiles/ablation_r04.md section 11.  SD_PLAN_TIMING=1 prints where a plan's seconds go.)
   if (m->nup < 0 || p > SD_MAX_PREFIX_BITS) {
     // generic (untiled) path: per-row rank/unrank on device
     m->p = -1; m->LS = 0;
@@ -466,6 +470,15 @@ int sd_build_plan(sd_model *m, int rank, int nranks, std::string &err) {
     }
   }
 
+  // SD_PLAN_TIMING=1: where the seconds of a plan go (stderr)
+  const bool timing = getenv("SD_PLAN_TIMING") != nullptr;
+  auto t_last = std::chrono::steady_clock::now();
+  auto tick = [&](const char *what) {
+    if (!timing) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[sd plan] %-28s %.3f s\n", what, std::chrono::duration<double>(now - t_last).count());
+    t_last = now;
+  };
   // all feasible tiles in natural (row) order
   std::vector<TileRef> tiles;
   const uint32_t nP = 1u << p;
@@ -477,6 +490,7 @@ int sd_build_plan(sd_model *m, int rank, int nranks, std::string &err) {
   std::sort(tiles.begin(), tiles.end(), [](const TileRef &a, const TileRef &b) { return a.base < b.base; });
   const size_t T = tiles.size();
   if (T == 0) { err = "empty basis"; return SD_EINTERNAL; }
+  tick("tiles enumerated + sorted");
 
   // ---- ownership of every tile ----
   // mode 0 ("range"): contiguous, tile-aligned basis-index ranges (what BASELINE.json's north star names).
@@ -625,6 +639,7 @@ int sd_build_plan(sd_model *m, int rank, int nranks, std::string &err) {
     }
   }
   m->shard_mode = mode;
+  tick("ownership");
 
   std::vector<int64_t> local_of(T, -1);
   m->addr.assign(nP, -1);
@@ -647,8 +662,10 @@ int sd_build_plan(sd_model *m, int rank, int nranks, std::string &err) {
       if (owner[k] > rank) { m->row_lo = m->row_hi = tiles[k].base; break; }
   }
 
+  tick("local tiles, addr");
   std::vector<int64_t> xcd_scratch((size_t)1 << p, -1);
   xcd_order(m, p, m->tile_prefix, m->tile_base, xcd_scratch);
+  tick("xcd_order");
 
   m->single_prefix = m->tile_prefix; m->single_base = m->tile_base;
 
@@ -798,8 +815,10 @@ int sd_build_plan(sd_model *m, int rank, int nranks, std::string &err) {
     m->seg_off[2 * SD_N_LEN_CLASS] = (int)m->single_prefix.size();
     m->n_interior = m->seg_off[SD_N_LEN_CLASS];
   }
+  tick("halo plan, length classes");
   m->tile_gbase.resize(m->tile_prefix.size());
   for (size_t k = 0; k < m->tile_prefix.size(); ++k) m->tile_gbase[k] = tile_base_global(m, m->tile_prefix[k]);
+  tick("global bases");
   return SD_OK;
 }
 
