@@ -35,7 +35,19 @@ def test_virtual_shards_random(pkg, seed, monkeypatch):
         monkeypatch.setenv("SD_SHARD_PACK", pack)
     kw = {"Jxy": float(rng.choice([1.0, 0.7])), "Jz": float(rng.normal()), "hz": float(rng.choice([0.0, 0.3])),
           "boundary": str(rng.choice(["open", "periodic"]))}
-    check_virtual_shards(pkg, L, nup, P, str(rng.choice(["range", "class"])), kw, need_interior=False)
+    make = None
+    if rng.random() < 0.4:
+        # the chain followed by a few further bonds anywhere (second neighbours, long range, wraps): the general-bond plan, whose
+        # prefix-prefix and mixed partner tiles may be another rank's
+        hop = [(i, i + 1, 0.5) for i in range(1, L)]
+        zz = [(i, i + 1, float(kw["Jz"])) for i in range(1, L)]
+        for _ in range(int(rng.integers(1, 6))):
+            i, j = sorted(rng.choice(np.arange(1, L + 1), size=2, replace=False).tolist())
+            hop.append((int(i), int(j), float(rng.normal()))); zz.append((int(i), int(j), float(rng.normal())))
+        for d in (2,) if rng.random() < 0.5 else ():
+            hop += [(i, i + d, 0.2) for i in range(1, L - d + 1)]
+        make = lambda: pkg.build_model(L, nup=nup, hopping=hop, zz=zz)      # noqa: E731
+    check_virtual_shards(pkg, L, nup, P, str(rng.choice(["range", "class"])), kw, need_interior=False, make=make)
 
 
 @pytest.mark.parametrize("L,P", [(13, 2), (14, 4), (15, 8), (16, 4), (17, 2)])
