@@ -227,3 +227,36 @@ def test_sharded8_time_evolution_vs_oracle(pkg, ranks8):
     assert np.array_equal(got, pkg.chebyshev_time_evolve(np.array(_psi0(L)), 0.5, pkg.apply_H, m1, cheb_n=CHEB_N, Ebounds=_bounds(L)))
     outs = vr.run(lambda r, op: op.krylov_time_evolve(parts[r], 0.25, kry_m=KRY_M))
     assert np.abs(vr.gather(outs) - _oracle_krylov(L)).max() <= 1e-11
+
+
+@pytest.mark.parametrize("mode", ["class"])
+def test_sharded4_recursions_on_a_j1j2_chain_vs_oracle(pkg, mode, monkeypatch):
+    """The collective recursions on a model beyond the chain (build_model with second-neighbour bonds: the general-bond plan, whose
+    prefix-prefix and mixed partner tiles arrive through the halo): four thread-ranks, KPM moments and Chebyshev / Krylov evolution
+    against the oracle on the unsharded model."""
+    from oracle import oracle as O
+    from virtual_ranks import VirtualRanks
+    O.build()
+    L, nup = 16, 8
+    hop, zz = [], []
+    for d, J in ((1, 1.0), (2, 0.4)):
+        for i in range(1, L - d + 1):
+            hop.append((i, i + d, 0.5 * J)); zz.append((i, i + d, J))
+    monkeypatch.setenv("SD_SUFFIX_BITS", "8")
+    r = O.build_model(L, nup=nup, hopping=hop, zz=zz)
+    vr = VirtualRanks(pkg, lambda ctx: pkg.build_model(L, nup=nup, hopping=hop, zz=zz, ctx=ctx), 4, mode)
+    try:
+        assert all(op.n_local > 0 for op in vr.ops) and any(op.n_halo > 0 for op in vr.ops)
+        rng = np.random.default_rng(5)
+        psi0 = rng.standard_normal(r.N) + 1j * rng.standard_normal(r.N)
+        psi0 /= np.linalg.norm(psi0)
+        a, b = pkg.rescaling_from_bounds(-0.5 * L, 0.4 * L)
+        parts = vr.scatter(psi0)
+        mus = vr.run(lambda k, op: op.kpm_moments(parts[k], 64, a, b))
+        assert np.abs(mus[0] - O.compute_chebyshev_moments(r, psi0, 64, a, b)).max() <= 1e-12
+        outs = vr.run(lambda k, op: op.chebyshev_time_evolve(parts[k], 0.5, cheb_n=30, Ebounds=(-0.5 * L, 0.4 * L)))
+        assert np.abs(vr.gather(outs) - O.chebyshev_time_evolve(r, psi0, 0.5, cheb_n=30, Ebounds=(-0.5 * L, 0.4 * L))).max() <= 1e-12
+        outs = vr.run(lambda k, op: op.krylov_time_evolve(parts[k], 0.25, kry_m=12))
+        assert np.abs(vr.gather(outs) - O.krylov_time_evolve(r, psi0, 0.25, kry_m=12)).max() <= 1e-11
+    finally:
+        vr.close()
