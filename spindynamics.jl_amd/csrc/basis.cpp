@@ -861,7 +861,7 @@ int sd_upload_model(sd_model *m, std::string &err) {
   d.full_ls = m->full_ls;
   d.fs_dbits = m->fs_dbits;
   for (int q = 0; q < SD_FS_MAX_RANKS; ++q) { d.fs_halo_off[q] = m->fs_halo_off[q]; d.fs_peer_lo[q] = m->fs_peer_lo[q]; }
-  d.nn_hops = (m->p >= 0 || m->full_ls > 0) ? count_nn_hops(m) : 0;
+  d.nn_hops = (m->p >= 0 || m->full_ls > 0 || m->nup >= 0) ? count_nn_hops(m) : 0;     // (per-row path of a sector: closed-form partner index of the chain bonds)
   d.field_zero = 1;
   for (double h : m->field) if (h != 0.0) d.field_zero = 0;
   // closed-form diagonal when it is bit-identical to the reference's sequential sum

@@ -769,19 +769,58 @@ __global__ __launch_bounds__(256) void k_apply_generic(sd_dev_model dm, double *
                                                        double *__restrict__ partials) {
   using V = typename VT<NC>::type;
   __shared__ double red[32];
+  // the binomials of the combinadic order in LDS (a sector's unrank / rank walk L of them per call), 64 x 64 entries
+  __shared__ int64_t lb[64 * 64];
   const V *__restrict__ psi = reinterpret_cast<const V *>(psi_);
   const bool full = dm.nup < 0;
+  const int L = dm.L;
+  if (!full) {
+    for (int i = threadIdx.x; i < 64 * 64; i += blockDim.x) {
+      const int n = i >> 6, k = i & 63;
+      lb[i] = (n <= L && k <= n) ? dm.binom[n * (SD_MAX_L + 1) + k] : 0;
+    }
+    __syncthreads();
+  }
+  auto bl = [&](int n, int k) -> int64_t { return (k < 0 || k > n) ? 0 : lb[(n << 6) + k]; };
+  auto unrank_l = [&](int64_t idx) {
+    uint64_t s = 0;
+    int r = dm.nup;
+    for (int k = 1; k <= L && r > 0; ++k) {
+      const int64_t c = bl(L - k, r - 1);
+      if (idx < c) { s |= (uint64_t)1 << (k - 1); --r; }
+      else idx -= c;
+    }
+    return s;
+  };
+  auto rank_l = [&](uint64_t s) {
+    int64_t idx = 0;
+    int r = dm.nup;
+    for (int k = 1; k <= L && r > 0; ++k) {
+      if ((s >> (k - 1)) & 1) --r;
+      else idx += bl(L - k, r - 1);
+    }
+    return idx;
+  };
+  const int nn = full ? 0 : dm.nn_hops;       // leading chain bonds (1,2),(2,3),...: the partner index in closed form
   EpiSums sums{0.0, 0.0};
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < dm.N; idx += stride) {
-    const uint64_t s = full ? (uint64_t)idx : unrank_g(dm, idx);
+    const uint64_t s = full ? (uint64_t)idx : unrank_l(idx);
     const V own = psi[idx];
     V acc = vscale(diag_of(dm, s), own);
-    for (int h = 0; h < dm.n_hop; ++h) {
+    // chain bond (b, b+1): the flip moves one up spin across one site, past nothing -- the index changes by C(L-b-1, u),
+    // u = ups beyond site b+1, upwards when site b holds the up spin; no rank walk
+    for (int b = 1; b <= nn; ++b)
+      if (((s >> (b - 1)) ^ (s >> b)) & 1) {
+        const int64_t d = lb[((L - b - 1) << 6) + __popcll(s >> (b + 1))];
+        const int64_t nidx = ((s >> (b - 1)) & 1) ? idx + d : idx - d;
+        acc = vadd_mul(acc, dm.hop_J[b - 1], psi[nidx]);
+      }
+    for (int h = nn; h < dm.n_hop; ++h) {
       const int bi = dm.hop_i[h] - 1, bj = dm.hop_j[h] - 1;
       if (((s >> bi) ^ (s >> bj)) & 1) {
         const uint64_t s2 = s ^ ((uint64_t)1 << bi) ^ ((uint64_t)1 << bj);
-        const int64_t nidx = full ? (int64_t)s2 : rank_g(dm, s2);
+        const int64_t nidx = full ? (int64_t)s2 : rank_l(s2);
         acc = vadd_mul(acc, dm.hop_J[h], psi[nidx]);
       }
     }

@@ -50,8 +50,10 @@ def sample_rows(model, n_random, seed):
     N = model.N
     rng = np.random.default_rng(seed)
     parts = [np.arange(0, min(N, 2048)), np.arange(max(0, N - 2048), N), rng.integers(0, N, n_random)]
-    lb, gb, ln = model.local_tiles()                      # tile boundaries of the device plan: rows on both sides of a few hundred of them
-    pick = rng.choice(len(gb), size=min(len(gb), 300), replace=False)
+    gb = []
+    if model.device_path == "tiled":                      # tile boundaries of the device plan: rows on both sides of a few hundred of them
+        _lb, gb, _ln = model.local_tiles()
+    pick = rng.choice(len(gb), size=min(len(gb), 300), replace=False) if len(gb) else []     # (the per-row path has no tiles)
     for t in pick:
         parts.append(np.arange(max(0, gb[t] - 3), min(N, gb[t] + 3)))
     return np.unique(np.concatenate(parts).astype(np.int64))
@@ -68,6 +70,9 @@ CASES = [
     (28, 14, {"ranges": ((1, 1.0), (2, 0.5))}, "c128", 12000),                       # J1-J2: the general-bond plan (streams, packed table, second LDS image)
     (28, 13, {"ranges": ((1, 1.0), (2, 0.5), (3, -0.3)), "boundary": "periodic"}, "f64", 12000),
     (26, 13, {"ranges": tuple((d, 1.0 / d ** 2) for d in range(1, 26))}, "c128", 6000),   # every pair, 1/r^2: 325 bonds
+    (40, 10, {}, "c128", 8000),                                                      # 2^28 prefixes: the per-row path (closed-form chain partners), N = 8.5e8
+    (44, 8, {"Jxy": 0.8, "Jz": 1.3, "hz": 0.1}, "f64", 8000),
+    (39, 7, {"boundary": "periodic"}, "c128", 8000),                                 # ... with the wrap bond through the rank walk
     (36, 18, {}, "f64", 8000),                                                       # config 5's sector whole on one GPU: N = 9.08e9 rows, past 2^32
 ]
 
