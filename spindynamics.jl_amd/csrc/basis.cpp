@@ -374,7 +374,18 @@ int sd_build_plan(sd_model *m, int rank, int nranks, std::string &err) {
   // (Prefix spaces beyond 2^26 -- dilute sectors of chains with L >= 39 at LS = 12 -- keep the per-row path: the plan's dense prefix
   // tables cost 13 B x 2^p on the host and its tile order visits all 2^p prefixes; measured with the cap at 28: L=40, nup=10 plans in
   // 110 s for an apply of ~50 instead of 528 ms, profiles/ablation_r04.md section 11.  SD_PLAN_TIMING=1 prints where a plan's seconds go.)
-  if (m->nup < 0 || p > SD_MAX_PREFIX_BITS) {
+  // Very dilute sectors: when the tiles hold fewer than 32 rows on average the per-workgroup set-up of the tiled kernel costs more
+  // than the per-row path's unrank (L=30, nup=6, 12 rows per tile: 3.2 against 12.2 G rows/s; L=36, nup=9, 36 rows per tile: 18.0 against
+  // 16.6 -- profiles/ablation_r04.md section 11).  Unsharded plans only: a shard is a union of tiles.  SD_FORCE_PER_ROW / SD_FORCE_TILED: A/B.
+  bool short_tiles = false;
+  if (m->nup >= 0 && p >= 0 && p <= SD_MAX_PREFIX_BITS && nranks == 1) {
+    double nt = 0;
+    for (int k = std::max(0, m->nup - LS); k <= std::min(p, m->nup); ++k) nt += (double)B(m, p, k);
+    short_tiles = nt > 0 && (double)m->N / nt < 32.0 && p >= 1;
+    if (getenv("SD_FORCE_PER_ROW")) short_tiles = true;
+    if (getenv("SD_FORCE_TILED")) short_tiles = false;
+  }
+  if (m->nup < 0 || p > SD_MAX_PREFIX_BITS || short_tiles) {
     // generic (untiled) path: per-row rank/unrank on device
     m->p = -1; m->LS = 0;
     m->row_lo = 0; m->row_hi = m->N; m->n_local = m->N;
