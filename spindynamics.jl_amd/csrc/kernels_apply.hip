@@ -66,6 +66,9 @@ namespace {
 #ifndef SD_SKIP_DEAD_C128
 #define SD_SKIP_DEAD_C128 0     // (round 4, wave-contiguous rows: A/B in profiles/ablation_r04.md)
 #endif
+#ifndef SD_SKIP_DEAD_C128_SHORT
+#define SD_SKIP_DEAD_C128_SHORT 1   // ... for the one-wave workgroups of the short tiles only (dilute sectors: most tiles fill one or two row groups)
+#endif
 #ifndef SD_LB_C128
 #define SD_LB_C128 4
 #endif
@@ -200,7 +203,7 @@ __global__ __launch_bounds__(BLOCK, (GEN ? SD_LB_GEN : NC == 2 ? SD_LB_C128 : SD
   // stay zero.  The range check would return zeros for them anyway, but every such load still costs the address unit its
   // cycles (TA busy 70 % of the launch, ablation_r03.md section 5).
   // Float64 only: measured -2...3 % there, but +5 % for ComplexF64 (round 3).
-  constexpr bool SKIP_DEAD = SD_SKIP_DEAD_ROWS && (NC == 1 || SD_SKIP_DEAD_C128);
+  constexpr bool SKIP_DEAD = SD_SKIP_DEAD_ROWS && (NC == 1 || SD_SKIP_DEAD_C128 || (SD_SKIP_DEAD_C128_SHORT == 1 && BLOCK == 64) || (SD_SKIP_DEAD_C128_SHORT == 2 && BLOCK <= 128));
   uint32_t live = 0;
   if (SKIP_DEAD) {
 #pragma unroll
