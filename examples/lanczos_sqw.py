@@ -30,3 +30,11 @@ print("S(pi, w) peaks at w = %.3f with %.5f;  S(q=0, w) max = %.2e (total S^z is
     omega[np.argmax(S[iq])], S[iq].max(), S[0].max()))
 
 assert S.shape == (len(q), len(omega)) and np.isfinite(S).all() and S.min() >= 0.0
+
+# the other two calls of the reference's README quick start: real-time evolution and the static structure factor
+t0 = time.time()
+psi_t = sd.time_evolve(model, psi0, 0.5, method="krylov")
+Sq = sd.structure_factor(model, psi0)
+print("time_evolve(:krylov, t = 0.5) + structure_factor: %.3f s   |<psi0|psi_t>| = %.12f   S(q = pi) = %.6f" % (
+    time.time() - t0, abs(np.vdot(psi0, psi_t)), Sq[max(Sq, key=lambda k: abs(k - np.pi) < 1e-12)]))
+assert abs(abs(np.vdot(psi0, psi_t)) - 1.0) < 1e-8          # an eigenstate only picks up a phase
