@@ -81,6 +81,8 @@ def bond_lists(L, kw):
     """(hopping, zz, field) of the model: XXZChain's lists (src/SpinModel.jl:63-90) or, with kw["ranges"], a build_model with bonds
     (i, i + d) of strength J for every (d, J) of the ranges, distance by distance (periodic: wrapped)"""
     hop, zz = [], []
+    if "lists" in kw:
+        return kw["lists"]
     if "ranges" in kw:
         for d, J in kw["ranges"]:
             for i in range(1, L + 1):
@@ -99,9 +101,9 @@ def bond_lists(L, kw):
 
 
 def make_model(pkg, L, nup, kw):
-    if "ranges" in kw:
-        hop, zz, _f = bond_lists(L, kw)
-        return pkg.build_model(L, nup=nup, hopping=hop, zz=zz)
+    if "ranges" in kw or "lists" in kw:
+        hop, zz, f = bond_lists(L, kw)
+        return pkg.build_model(L, nup=nup, hopping=hop, zz=zz, onsite_field=np.asarray(f, dtype=float))
     return pkg.XXZChain(L, nup=nup, **kw)
 
 
@@ -268,3 +270,49 @@ def test_one_rank_of_the_sharded_L32_apply_on_a_random_vector_equals_the_unshard
     torch.cuda.synchronize()
     assert bool(torch.equal(out, y[rows]))
     assert op.n_halo > 0 and (op.n_interior_tiles > 0 or mode == "range")      # (an inner index range of eight has no interior tile)
+
+
+def _random_big_model(rng):
+    """a sector of 10^6..3*10^8 rows with random filling, couplings and extra bonds: whatever plan the library picks for it"""
+    from math import comb as C
+    while True:
+        L = int(rng.integers(22, 37))
+        nup = int(rng.integers(2, L - 1))
+        if 1e6 <= C(L, nup) <= 3e8:
+            break
+    kind = int(rng.integers(0, 4))
+    Jz = float(rng.choice([1.0, 0.5, float(rng.normal())]))
+    hz = float(rng.choice([0.0, 0.0, 0.25]))
+    hop = [(i, i + 1, 0.5) for i in range(1, L)] if kind != 1 else [(i, i + 1, float(rng.normal())) for i in range(1, L)]
+    zz = [(i, i + 1, Jz) for i in range(1, L)]
+    if kind == 2:                                   # periodic chain
+        hop.append((L, 1, hop[0][2])); zz.append((L, 1, Jz))
+    if kind == 3:                                   # further bonds: a second-neighbour ladder and a few random pairs
+        hop += [(i, i + 2, 0.2) for i in range(1, L - 1)]
+        zz += [(i, i + 2, 0.4) for i in range(1, L - 1)]
+        for _ in range(int(rng.integers(0, 4))):
+            i, j = sorted(rng.choice(np.arange(1, L + 1), size=2, replace=False).tolist())
+            hop.append((int(i), int(j), float(rng.normal()))); zz.append((int(i), int(j), float(rng.normal())))
+    return L, nup, {"lists": (hop, zz, [hz] * L)}
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("SD_BIG_FUZZ_N", "10"))))
+def test_random_large_sectors_sampled_rows_bit_exact(pkg, seed):
+    """Seeded random sectors of 10^6 .. 3*10^8 rows (any filling: tiled plans with long and with short tiles, the per-row path, the
+    general-bond plan), random couplings, both element types: sampled rows against the numpy row loop, to the bit."""
+    import torch
+    rng = np.random.default_rng(9000 + seed)
+    L, nup, kw = _random_big_model(rng)
+    dtype = str(rng.choice(["c128", "f64"]))
+    model = make_model(pkg, L, nup, kw)
+    psi = random_vector(pkg, model, model.N, dtype, 77 + seed)
+    out = torch.empty_like(psi)
+    pkg.apply_H(out, psi, model)
+    torch.cuda.synchronize()
+    rows = sample_rows(model, 3000, seed=seed)
+    _own_re, _own_im, val_re, val_im = reference_rows(psi, rows, L, nup, kw, dtype)
+    got = out[torch.from_numpy(rows).cuda()].cpu().numpy()
+    if dtype == "c128":
+        assert np.array_equal(got.real, val_re) and np.array_equal(got.imag, val_im), (L, nup, model.device_path)
+    else:
+        assert np.array_equal(got, val_re), (L, nup, model.device_path)
