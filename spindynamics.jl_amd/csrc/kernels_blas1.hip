@@ -11,7 +11,7 @@ using sd_dev::block_reduce2;
 
 namespace {
 
-constexpr int RED_BLOCKS = 2048;
+constexpr int RED_BLOCKS = 16384;    // most blocks of a streaming pass (= partial pairs of its reduction): long streams run 5-10 % faster with 16384 blocks than with 2048 (profiles/probes/stream_mix_probe.hip)
 constexpr int BS = 256;
 
 // conj(x).y for complex (nc=2) or x.y for real (nc=1); n2 = number of double2 elements when vectorised.
@@ -873,6 +873,8 @@ int sd_k_sub2(sd_ctx *ctx, double *w, const double *v, const double *u, int64_t 
 int sd_k_lanczos_fold(sd_ctx *ctx, double *t, const double *uc, const double *up, int64_t N, int form, const double *dot_dev,
                       const double *n2c_dev, const double *n2p_dev, double *store_alpha, double *store_bc, double *n2_out) {
   // see k_lanczos_fold; N complex elements; |w|^2 -> n2_out[0] (n2_out[1] = 0), a device address
+  // up to 16384 blocks: a 3-read : 1-write stream of this length reaches 5.5 TB/s with them against 5.2 with 2048
+  // (profiles/probes/stream_mix_probe.hip; the 1 : 1 copy of the same width: 5.9)
   int rc = sd_ensure_partials(ctx, 2 * RED_BLOCKS); if (rc) return rc;
   unsigned nb = grid_for(N);
   if (nb > RED_BLOCKS) nb = RED_BLOCKS;
