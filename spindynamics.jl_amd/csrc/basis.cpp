@@ -354,6 +354,7 @@ int sd_build_plan(sd_model *m, int rank, int nranks, std::string &err) {
   m->suf_states.clear(); m->suf_rank.clear(); m->suf_off.clear(); m->suf_part.clear();
   m->recv_slabs.clear(); m->send_slabs.clear();
   m->n_halo = 0; m->max_tile_len = 0;
+  m->n_short = 0; m->short_off = 0; m->n_short_multi = 0;
 
   const int L = m->L;
   int LS = std::min(L, suffix_bits_from_env());
@@ -374,14 +375,16 @@ int sd_build_plan(sd_model *m, int rank, int nranks, std::string &err) {
   // (Prefix spaces beyond 2^26 -- dilute sectors of chains with L >= 39 at LS = 12 -- keep the per-row path: the plan's dense prefix
   // tables cost 13 B x 2^p on the host and its tile order visits all 2^p prefixes; measured with the cap at 28: L=40, nup=10 plans in
   // 110 s for an apply of ~50 instead of 528 ms, profiles/ablation_r04.md section 11.  SD_PLAN_TIMING=1 prints where a plan's seconds go.)
-  // Very dilute sectors: when the tiles hold fewer than 32 rows on average the per-workgroup set-up of the tiled kernel costs more
-  // than the per-row path's unrank (L=30, nup=6, 12 rows per tile: 3.2 against 12.2 G rows/s; L=36, nup=9, 36 rows per tile: 18.0 against
-  // 16.6 -- profiles/ablation_r04.md section 11).  Unsharded plans only: a shard is a union of tiles.  SD_FORCE_PER_ROW / SD_FORCE_TILED: A/B.
+  // Small, very dilute sectors: with fewer than 32 rows per tile on average and fewer than 1.5 M rows in all the apply is a handful of
+  // launches of mostly one-row workgroups, and the per-row path's single launch is as fast or faster (L=30, nup=6: 12.0 against 9.3 G
+  // rows/s; L=32, nup=6: 13.4 against 13.2; larger dilute sectors go to the tiles, whose short ones have a kernel of their own:
+  // L=36, nup=6: 17.1 against 14.2 -- profiles/ablation_r04.md section 11).  Unsharded plans only: a shard is a union of tiles.
+  // SD_FORCE_PER_ROW / SD_FORCE_TILED: A/B.
   bool short_tiles = false;
   if (m->nup >= 0 && p >= 0 && p <= SD_MAX_PREFIX_BITS && nranks == 1) {
     double nt = 0;
     for (int k = std::max(0, m->nup - LS); k <= std::min(p, m->nup); ++k) nt += (double)B(m, p, k);
-    short_tiles = nt > 0 && (double)m->N / nt < 32.0 && p >= 1;
+    short_tiles = nt > 0 && (double)m->N / nt < 32.0 && p >= 1 && m->N < 1500000;
     if (getenv("SD_FORCE_PER_ROW")) short_tiles = true;
     if (getenv("SD_FORCE_TILED")) short_tiles = false;
   }
@@ -810,7 +813,23 @@ int sd_build_plan(sd_model *m, int rank, int nranks, std::string &err) {
     };
     std::vector<std::vector<uint32_t>> sp(2 * SD_N_LEN_CLASS);
     std::vector<std::vector<int64_t>> sb(2 * SD_N_LEN_CLASS);
+    // Short tiles (<= 16 rows) of an unsharded plan go to k_apply_short when they are many: a workgroup per one-row or twelve-row tile
+    // is all set-up (L=36, nup=9: 2.0 M of 2.6 M tiles hold 11 % of the rows and took 70 % of the apply: 4.13 -> 2.36 ms).  Many = at least
+    // 8192 and a fifth of all tiles (half filling at L=32: 40 000 of 1 M, not worth two more launches).  SD_SHORT_TILES=0 keeps them in their
+    // length class; =1 moves them whatever their number.
+    std::vector<uint32_t> short_p; std::vector<int64_t> short_b;
+    bool use_short = false;
+    if (nranks == 1 && m->LS <= 12 && p >= 1) {
+      size_t n_sh = 0;
+      for (size_t k = 0; k < ns; ++k) if (B(m, m->LS, m->nup - __builtin_popcount(m->single_prefix[k])) <= 16) ++n_sh;
+      use_short = n_sh >= 8192 && 5 * n_sh >= ns;
+      if (const char *e = getenv("SD_SHORT_TILES")) use_short = atoi(e) != 0 && n_sh > 0;
+    }
     for (size_t k = 0; k < ns; ++k) {
+      if (use_short && B(m, m->LS, m->nup - __builtin_popcount(m->single_prefix[k])) <= 16) {
+        short_p.push_back(m->single_prefix[k]); short_b.push_back(m->single_base[k]);
+        continue;
+      }
       // longest class first: the short-tile launches fill the tail of the long one
       const int sgi = boundary[k] * SD_N_LEN_CLASS + (SD_N_LEN_CLASS - 1 - cls_of(m->single_prefix[k]));
       sp[sgi].push_back(m->single_prefix[k]); sb[sgi].push_back(m->single_base[k]);
@@ -825,6 +844,16 @@ int sd_build_plan(sd_model *m, int rank, int nranks, std::string &err) {
     }
     m->seg_off[2 * SD_N_LEN_CLASS] = (int)m->single_prefix.size();
     m->n_interior = m->seg_off[SD_N_LEN_CLASS];
+    // the short tiles follow the class segments (in natural order: consecutive tiles, consecutive rows)
+    // ... those of 2..16 rows first, then the one-row tiles
+    m->short_off = (int)m->single_prefix.size(); m->n_short = (int)short_p.size(); m->n_short_multi = 0;
+    for (int pass = 0; pass < 2; ++pass)
+      for (size_t k = 0; k < short_p.size(); ++k) {
+        const bool one = B(m, m->LS, m->nup - __builtin_popcount(short_p[k])) == 1;
+        if (one != (pass == 1)) continue;
+        m->single_prefix.push_back(short_p[k]); m->single_base.push_back(short_b[k]);
+        if (pass == 0) ++m->n_short_multi;
+      }
   }
   tick("halo plan, length classes");
   m->tile_gbase.resize(m->tile_prefix.size());
@@ -939,6 +968,7 @@ int sd_upload_model(sd_model *m, std::string &err) {
     if ((rc = up(m, m->pack_len, &d.pack_len, err))) return rc;
     d.n_singles = (int)m->single_prefix.size();
     d.n_interior = m->n_interior; d.tile_off = 0;
+    d.n_short = m->n_short; d.short_off = m->short_off; d.n_short_multi = m->n_short_multi;
     m->single_rec.resize(m->single_prefix.size());
     for (size_t k = 0; k < m->single_prefix.size(); ++k) {
       const uint32_t P = m->single_prefix[k];

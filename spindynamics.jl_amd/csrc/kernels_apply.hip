@@ -836,6 +836,88 @@ __global__ __launch_bounds__(256) void k_apply_generic(sd_dev_model dm, double *
   }
 }
 
+// =====================================================================
+// short tiles: sixteen lanes per tile, one row per lane
+// =====================================================================
+// The tiles of suffix fillings 0, 1, LS-1 and LS hold 1 or LS <= 12 rows; in a dilute sector they are most of the tiles (L=36,
+// nup=9: 2.0 M of 2.6 M) and a workgroup each is nearly all set-up.  Here a 256-thread block takes sixteen of them: lane i of a
+// 16-lane group owns row i of the group's tile -- configuration from the tile record and the suffix table, diagonal by diag_of (or
+// the cached value), a chain bond's partner row by the closed form of the combinadic order, idx +- C(L-b-1, u) (SURVEY appendix B;
+// unsharded plans: local row = global row), other bonds by a rank walk over binomials held in LDS.  Same per-row arithmetic and
+// order as everywhere else; the tile's two partial sums are reduced over its sixteen lanes and filed under the tile's index.
+template <int NC, int LPT>      // LPT lanes per tile: 16 (tiles of 2..16 rows) or 1 (one-row tiles)
+__global__ __launch_bounds__(256) void k_apply_short(sd_dev_model dm, double *__restrict__ out_, const double *__restrict__ psi_, int epi,
+                                                     sd_epi_args ea, double *__restrict__ partials, int first, int count) {
+  using V = typename VT<NC>::type;
+  __shared__ int64_t lb[64 * 64];
+  if (ea.batch > 1) {                                          // vector blockIdx.y of a batch (as in k_apply_tiled)
+    const int64_t boff = (int64_t)blockIdx.y * ea.bstride * NC;
+    psi_ += boff; out_ += boff;
+    if (ea.prev) ea.prev = (const double *)ea.prev + boff;
+    if (ea.phi) ea.phi = (const double *)ea.phi + boff;
+    if (ea.accv) ea.accv = (double *)ea.accv + boff;
+    partials += 2 * (size_t)blockIdx.y * (size_t)dm.n_singles;
+    ea.negate = (ea.negate >> blockIdx.y) & 1;
+  }
+  const V *__restrict__ psi = reinterpret_cast<const V *>(psi_);
+  const int L = dm.L, p = dm.p;
+  for (int i = threadIdx.x; i < 64 * 64; i += blockDim.x) {    // (paid once per block: the blocks stride over the tile list)
+    const int n = i >> 6, k = i & 63;
+    lb[i] = (n <= L && k <= n) ? dm.binom[n * (SD_MAX_L + 1) + k] : 0;
+  }
+  __syncthreads();
+  auto bl = [&](int n, int k) -> int64_t { return (k < 0 || k > n) ? 0 : lb[(n << 6) + k]; };
+  auto rank_l = [&](uint64_t s) {
+    int64_t idx = 0;
+    int r = dm.nup;
+    for (int k = 1; k <= L && r > 0; ++k) {
+      if ((s >> (k - 1)) & 1) --r;
+      else idx += bl(L - k, r - 1);
+    }
+    return idx;
+  };
+  constexpr int TPB = 256 / LPT;                               // tiles of a block per sweep
+  const int i = threadIdx.x % LPT;
+  const int nn = dm.nn_hops;
+  const int sweeps = (count + (int)gridDim.x * TPB - 1) / ((int)gridDim.x * TPB);      // the same for every lane: the shuffles below stay converged
+  for (int sw = 0; sw < sweeps; ++sw) {
+    const int g = (sw * (int)gridDim.x + (int)blockIdx.x) * TPB + (int)threadIdx.x / LPT;
+    const bool have_tile = g < count;
+    const int tix = first + (have_tile ? g : 0);
+    const sd_tile_rec rec = dm.single_rec[tix];
+    EpiSums sums{0.0, 0.0};
+    if (have_tile && i < rec.len) {
+      const int64_t idx = rec.base + i;
+      const uint64_t s = (uint64_t)rec.prefix | ((uint64_t)dm.suf_states[rec.suf_off + i] << p);
+      const V own = psi[idx];
+      V acc = vscale(dm.diag_cache ? dm.diag_cache[idx] : diag_of(dm, s), own);
+      for (int b = 1; b <= nn; ++b)
+        if (((s >> (b - 1)) ^ (s >> b)) & 1) {
+          const int64_t d = lb[((L - b - 1) << 6) + __popcll(s >> (b + 1))];
+          const int64_t nidx = ((s >> (b - 1)) & 1) ? idx + d : idx - d;
+          acc = vadd_mul(acc, dm.hop_J[b - 1], psi[nidx]);
+        }
+      for (int h = nn; h < dm.n_hop; ++h) {
+        const int bi = dm.hop_i[h] - 1, bj = dm.hop_j[h] - 1;
+        if (((s >> bi) ^ (s >> bj)) & 1) {
+          const uint64_t s2 = s ^ ((uint64_t)1 << bi) ^ ((uint64_t)1 << bj);
+          acc = vadd_mul(acc, dm.hop_J[h], psi[rank_l(s2)]);
+        }
+      }
+      epilogue<NC>(epi, ea, idx, acc, own, out_, sums);
+    }
+    if (epi_has_sums(epi)) {
+      double a = sums.s0, b = sums.s1;
+      if (LPT > 1)
+        for (int off = LPT / 2; off > 0; off >>= 1) {          // over the tile's lanes, fixed order
+          a += __shfl_down(a, off, LPT);
+          b += __shfl_down(b, off, LPT);
+        }
+      if (have_tile && i == 0) { partials[2 * (size_t)tix] = a; partials[2 * (size_t)tix + 1] = b; }
+    }
+  }
+}
+
 // epilogue alone, for H psi produced by a caller's operator (sd_ctx_set_apply_callback): same arithmetic per element as the
 // fused form; out may be hpsi
 template <int NC>
@@ -1045,6 +1127,20 @@ int sd_launch_apply(sd_ctx *ctx, const sd_model *m, int dtype, void *out, const 
                            : launch_tiled<1, false>(ctx, dm, cnt, cls, shmem, (double *)out, (const double *)psi, epi, ea, seg_max);
       }
       if (rc) return rc;
+      if (dm.n_short > 0 && part == 0) {          // the short tiles of an unsharded plan (k_apply_short)
+        const unsigned by = ea.batch > 1 ? (unsigned)ea.batch : 1u;
+        auto blocks = [](int tiles, int per_block) { return (unsigned)std::min(4096, std::max(1, (tiles + per_block - 1) / per_block)); };
+        const int n16 = dm.n_short_multi, n1 = dm.n_short - dm.n_short_multi;
+        if (n16 > 0) {
+          if (dtype == SD_C128) hipLaunchKernelGGL((k_apply_short<2, 16>), dim3(blocks(n16, 16), by), dim3(256), 0, ctx->stream, dm, (double *)out, (const double *)psi, epi, ea, ctx->d_partials, dm.short_off, n16);
+          else hipLaunchKernelGGL((k_apply_short<1, 16>), dim3(blocks(n16, 16), by), dim3(256), 0, ctx->stream, dm, (double *)out, (const double *)psi, epi, ea, ctx->d_partials, dm.short_off, n16);
+        }
+        if (n1 > 0) {
+          if (dtype == SD_C128) hipLaunchKernelGGL((k_apply_short<2, 1>), dim3(blocks(n1, 256), by), dim3(256), 0, ctx->stream, dm, (double *)out, (const double *)psi, epi, ea, ctx->d_partials, dm.short_off + n16, n1);
+          else hipLaunchKernelGGL((k_apply_short<1, 1>), dim3(blocks(n1, 256), by), dim3(256), 0, ctx->stream, dm, (double *)out, (const double *)psi, epi, ea, ctx->d_partials, dm.short_off + n16, n1);
+        }
+        SD_HIP(ctx, hipGetLastError());
+      }
     }
     if (sums && part != 1 && !ea.no_reduce) {
       int rc2 = ea.batch > 1 ? sd_reduce_pairs_batched(ctx, (int64_t)dm.n_singles, ea.batch, ea.sums_dst, ea.sums_bstride)

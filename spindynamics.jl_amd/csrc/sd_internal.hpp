@@ -160,6 +160,11 @@ struct sd_dev_model {
   const sd_gbond *gen;
   const uint32_t *gen_ss_part;
   const uint16_t *mix_part;
+  // Short tiles (at most 16 rows: suffix fillings 0, 1, LS-1, LS -- most of the tiles of a dilute sector) of an unsharded plan, taken
+  // out of the length classes: single_rec[short_off .. short_off + n_short) run through k_apply_short, sixteen lanes per tile, one row
+  // per lane, partner rows by the closed form of the combinadic order instead of a workgroup per tile.  n_short = 0: none.
+  int n_short, short_off;
+  int n_short_multi;             // the first n_short_multi of them hold 2..16 rows (sixteen lanes per tile), the rest one row (one lane per tile)
 };
 
 #define SD_N_LEN_CLASS 5   // tile length classes: workgroups of 64, 128, 256, 512, 1024 threads (x 4 rows)
@@ -188,6 +193,7 @@ struct sd_model {
   std::vector<uint8_t> suf_dg;
   int wrap_hop = -1, wrap_pb = 0;   // see sd_dev_model
   std::vector<sd_gbond> gen;        // general-bond plan (see sd_dev_model), empty: none
+  int n_short = 0, short_off = 0, n_short_multi = 0;   // short tiles at the end of the single-tile lists (see sd_dev_model)
   std::vector<uint32_t> gen_ss_part;
   std::vector<uint16_t> mix_part;
   std::vector<int64_t> far_base;
