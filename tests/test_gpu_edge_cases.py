@@ -26,6 +26,9 @@ def test_device_paths_reported(pkg):
     assert pkg.XXZChain(8, nup=None).device_path == "generic"
     assert pkg.XXZChain(14, nup=None).device_path == "full-tiled"   # 2^10-row tiles of the full basis
     assert pkg.XXZChain(50, nup=3).device_path == "generic"     # 2^38 prefix tiles would not fit a table
+    assert pkg.XXZChain(30, nup=6).device_path == "generic"     # small and very dilute (12 rows per tile, 0.6 M rows): one launch of the per-row kernel
+    assert pkg.XXZChain(30, nup=24).device_path == "generic"    # ... the same sector seen from the other side
+    assert pkg.XXZChain(32, nup=8).device_path == "tiled"       # dilute but large: tiles, the short ones through k_apply_short
 
 
 def test_boundary_errors(pkg):
