@@ -686,3 +686,32 @@ def test_recursions_on_a_chain_with_second_neighbour_bonds_vs_oracle(pkg, O, L, 
     q, omega = pkg.momenta(m), np.arange(0.0, 4.0, 0.05)
     S = pkg.kpm_sqw(gs2, m, q, omega, a=a, b=b, kpm_m=96)
     assert np.abs(S - O.kpm_sqw(r, gs2, q, omega, a, b, kpm_m=96)).max() <= 1e-8 * max(1.0, np.abs(S).max())
+
+
+@pytest.mark.parametrize("L,nup,bc", [(20, 3, "open"), (22, 19, "periodic")])
+def test_recursions_on_the_per_row_path_vs_oracle(pkg, O, L, nup, bc):
+    """A small, very dilute sector runs through the per-row kernel (closed-form chain partners; every fused store of the recursions goes
+    through its epilogue too): Lanczos, ground state, Krylov, Chebyshev, KPM moments and S(q,w) against the oracle."""
+    m = pkg.XXZChain(L, Jxy=0.9, Jz=1.3, nup=nup, boundary=bc)
+    r = O.XXZChain(L, Jxy=0.9, Jz=1.3, nup=nup, boundary=bc)
+    assert m.device_path == "generic"
+    p0 = cvec(m.N, 1)
+    al, be, nv = pkg.lanczos_tridiag(pkg.apply_H, m, p0, lanc_m=15)
+    al2, be2, nv2 = O.lanczos_tridiag(r, p0, lanc_m=15)
+    assert np.abs(al - al2).max() <= 1e-9 and np.abs(be - be2).max() <= 1e-9 and abs(nv - nv2) <= 1e-12 * nv2
+    x0 = np.random.default_rng(4).standard_normal(m.N)
+    E, gs = pkg.lanczos_groundstate(pkg.apply_H, m, lanc_m=60, psi0=x0)
+    E2, gs2 = O.lanczos_groundstate(r, x0, lanc_m=60)
+    assert abs(E - E2) <= 1e-10
+    psi0 = cvec(m.N, 5)
+    psi0 /= np.linalg.norm(psi0)
+    assert np.abs(pkg.krylov_time_evolve(psi0, 0.4, pkg.apply_H, m, kry_m=30) - O.krylov_time_evolve(r, psi0, 0.4, kry_m=30)).max() <= 1e-11
+    got = pkg.chebyshev_time_evolve(psi0, 0.4, pkg.apply_H, m, cheb_n=80, Ebounds=(-L / 2, L / 2))
+    assert np.abs(got - O.chebyshev_time_evolve(r, psi0, 0.4, cheb_n=80, Ebounds=(-L / 2, L / 2))).max() <= 1e-14
+    a, b = O.rescaling_from_bounds(-L / 2, L / 2)
+    phi = O.Sz_q_vector(r, gs2, np.pi)
+    phi /= np.linalg.norm(phi)
+    assert np.abs(pkg.compute_chebyshev_moments(pkg.apply_H, phi, 120, a, b, m) - O.compute_chebyshev_moments(r, phi, 120, a, b)).max() <= 1e-12
+    q, omega = pkg.momenta(m), np.arange(0.0, 4.0, 0.05)
+    S = pkg.kpm_sqw(gs2, m, q, omega, a=a, b=b, kpm_m=96)
+    assert np.abs(S - O.kpm_sqw(r, gs2, q, omega, a, b, kpm_m=96)).max() <= 1e-8 * max(1.0, np.abs(S).max())
