@@ -715,3 +715,29 @@ def test_recursions_on_the_per_row_path_vs_oracle(pkg, O, L, nup, bc):
     q, omega = pkg.momenta(m), np.arange(0.0, 4.0, 0.05)
     S = pkg.kpm_sqw(gs2, m, q, omega, a=a, b=b, kpm_m=96)
     assert np.abs(S - O.kpm_sqw(r, gs2, q, omega, a, b, kpm_m=96)).max() <= 1e-8 * max(1.0, np.abs(S).max())
+
+
+def test_recursions_with_the_short_tile_kernel_vs_oracle(pkg, O, monkeypatch):
+    """SD_SHORT_TILES=1 moves every tile of at most 16 rows to k_apply_short whatever their number: its per-tile partial sums feed the
+    Lanczos dot, the KPM step and the batched momenta exactly like the tiles' own."""
+    monkeypatch.setenv("SD_SHORT_TILES", "1")
+    monkeypatch.setenv("SD_SUFFIX_BITS", "10")
+    L, nup = 18, 5
+    m = pkg.XXZChain(L, Jxy=1.0, Jz=0.8, nup=nup)
+    r = O.XXZChain(L, Jxy=1.0, Jz=0.8, nup=nup)
+    assert m.device_path == "tiled"
+    psi = cvec(m.N, 3)
+    out = np.empty_like(psi)
+    pkg.apply_H(out, psi, m)
+    assert np.array_equal(out, O.apply_H(r, psi))
+    al, be, _ = pkg.lanczos_tridiag(pkg.apply_H, m, psi, lanc_m=20)
+    al2, be2, _ = O.lanczos_tridiag(r, psi, lanc_m=20)
+    assert np.abs(al - al2).max() <= 1e-9 and np.abs(be - be2).max() <= 1e-9
+    x0 = np.random.default_rng(4).standard_normal(m.N)
+    _, gs = O.lanczos_groundstate(r, x0, lanc_m=60)
+    a, b = O.rescaling_from_bounds(-L / 2, L / 2)
+    q, omega = pkg.momenta(m), np.arange(0.0, 4.0, 0.05)
+    S = pkg.kpm_sqw(gs, m, q, omega, a=a, b=b, kpm_m=96)                      # the momenta in one batch
+    assert np.abs(S - O.kpm_sqw(r, gs, q, omega, a, b, kpm_m=96)).max() <= 1e-8 * max(1.0, np.abs(S).max())
+    Sl = pkg.lanczos_sqw(gs, m, q[1:5], omega, lanc_m=12, eta=0.05)
+    assert np.abs(Sl - O.lanczos_sqw(r, gs, q[1:5], omega, lanc_m=12, eta=0.05)).max() <= 1e-8 * max(1.0, np.abs(Sl).max())
